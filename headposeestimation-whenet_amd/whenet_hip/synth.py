@@ -1,0 +1,43 @@
+"""Seeded synthetic 224x224 RGB uint8 head crops (there is no dataset in the reference and
+no network): the inputs every parity test and bench line in this repo is quoted on.
+
+  noise_crops   iid uniform bytes -- BASELINE.md §4 / SURVEY.md §8d: the throughput input.
+  scene_crops   low-frequency colour fields + blobs + edges: crops whose deep features
+                differ from one another the way real head crops do (iid noise crops all
+                look alike to a CNN, which would make the parity tests insensitive).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+IMG = 224
+
+
+def noise_crops(n: int, seed: int = 0) -> np.ndarray:
+    return np.random.default_rng(seed).integers(0, 256, (n, IMG, IMG, 3), dtype=np.uint8)
+
+
+def scene_crops(n: int, seed: int = 0) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, IMG), np.linspace(-1, 1, IMG), indexing="ij")
+    out = np.empty((n, IMG, IMG, 3), dtype=np.uint8)
+    for i in range(n):
+        img = np.zeros((IMG, IMG, 3))
+        base = rng.uniform(0.1, 0.9, size=3)
+        grad = rng.normal(0, 0.25, size=(2, 3))
+        img += base + yy[..., None] * grad[0] + xx[..., None] * grad[1]
+        for _ in range(int(rng.integers(2, 6))):            # plane waves
+            f = rng.uniform(0.5, 9.0, size=2) * rng.choice([-1, 1], size=2)
+            ph = rng.uniform(0, 2 * np.pi)
+            amp = rng.normal(0, 0.15, size=3)
+            img += np.cos(np.pi * (f[0] * yy + f[1] * xx) + ph)[..., None] * amp
+        for _ in range(int(rng.integers(1, 5))):            # soft-edged ellipses ("heads")
+            cy, cx = rng.uniform(-0.7, 0.7, size=2)
+            ry, rx = rng.uniform(0.15, 0.8, size=2)
+            d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+            m = 1.0 / (1.0 + np.exp((d - 1.0) * rng.uniform(4, 40)))
+            col = rng.uniform(0, 1, size=3)
+            img = img * (1 - m[..., None]) + col * m[..., None]
+        img += rng.normal(0, rng.uniform(0.0, 0.06), size=img.shape)   # sensor noise
+        out[i] = np.clip(np.rint(img * 255), 0, 255).astype(np.uint8)
+    return out
