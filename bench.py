@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the WHENet HIP path on MI355X -- prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f16|f32]
+
+A "step" is one pass of the hot path (uint8 crops resident in HBM -> yaw/pitch/roll,
+argmax, logits) over one batch of B synthetic crops per GPU.  Default workload:
+BASELINE.json configs[2] -- batch=64, 224x224, fp16 on one MI355X (the configuration the
+"crops/sec at batch 64" metric is quoted on); at N>1 the same per-GPU batch on every rank
+(configs[3], weak scaling, no data-path collective).  For N>1 the driver launches this file
+under torch.distributed.run (one rank per GPU, RCCL); run directly with --gpus N>1 it
+re-launches itself that way.
+
+Extra objects on the line:
+  roofline      dominant kernel: algorithmic bytes / HIP-event duration, per launch
+                (whenet_profile(): event pair around every launch, on the kernels' stream,
+                eager pass run right after the timed region) vs 8 TB/s HBM
+  cpu_baseline  the float32 torch-CPU restatement of the reference path ("port": the true
+                Keras path cannot run here), timed on this box's host cores, rank 0, N=1
+  latency_b1    configs[1]: batch=1 fp32 single-crop latency (median / p99), N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch  # first: one HIP runtime in the process (its libamdhip64 is shared with libwhenet_hip)
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "headposeestimation-whenet_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+PATH_BOUND_CROPS_S = {          # BASELINE.md §2, per GPU, f16, 6.29 TB/s
+    "layer_granular": 227280.0, "mbconv_2kernel_fusion": 453209.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--profile-iters", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def relaunch(args) -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_baseline(seconds: float):
+    """Reference-faithful CPU path (oracle/whenet_torch.py: float64 normalise, batch_size=8
+    chunks, numpy decode) on the host cores; bounded sample."""
+    from whenet_hip import weights as W, synth
+    from oracle.whenet_torch import TorchWHENet
+    m = TorchWHENet(W.synthetic(1234))
+    crops = synth.noise_crops(8, seed=0)
+    m.get_angle(crops.copy())                      # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        m.get_angle(crops.copy())
+        done += crops.shape[0]
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": done / el, "unit": "crops/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{done} crops as batches of 8 (whenet.py:27 batch_size=8) in {el:.1f} s; torch-CPU f32 "
+                      f"restatement of whenet.py:22-34 incl. float64 normalise + numpy decode",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        sys.exit(relaunch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from whenet_hip import _lib, synth, weights as W
+    from whenet_hip.shard import broadcast_bytes
+
+    # weights: rank 0 builds the seeded synthetic snapshot; RCCL broadcast to the others
+    blob = W.pack(W.synthetic(1234)) if rank == 0 else None
+    if distributed:
+        blob = broadcast_bytes(blob, 0, dev)
+    dt = _lib.F16 if args.dtype == "f16" else _lib.F32
+    h = _lib.Handle(blob, device=local_rank, dtype=dt)
+    if args.no_graph:
+        h.set_option("graph", 0)
+
+    B = args.batch
+    crops = synth.noise_crops(B, seed=rank)        # default_rng(seed) uint8
+    d_crops = torch.from_numpy(crops).to(dev)
+    d_ypr = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+    d_am = torch.zeros((B, 3), dtype=torch.int32, device=dev)
+    d_lg = torch.zeros((B, 252), dtype=torch.float32, device=dev)
+
+    def step():
+        h.forward_device(d_crops.data_ptr(), B, d_ypr.data_ptr(), d_am.data_ptr(), d_lg.data_ptr())
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    fence()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    value = world * B * args.steps / el
+
+    # ---- per-kernel roofline (HIP events around every launch, same stream, eager) ----------
+    stats = h.profile(d_crops.data_ptr(), B, args.profile_iters)
+    by_kernel = {}
+    for s in stats:
+        k = by_kernel.setdefault(s["kernel"], {"us": 0.0, "bytes": 0.0, "flops": 0.0, "launches": 0, "kind": s["kind"]})
+        k["us"] += s["avg_us"]
+        k["bytes"] += s["alg_bytes"]
+        k["flops"] += s["alg_flops"]
+        k["launches"] += 1
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["us"])
+    achieved = dom["bytes"] / (dom["us"] * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": dom_name, "launches_per_step": dom["launches"],
+                "avg_launch_us": dom["us"] / dom["launches"],
+                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+                "tflops": dom["flops"] / (dom["us"] * 1e-6) / 1e12,
+                "method": "hipEvent pair around every launch on the kernels' stream, eager pass after the timed region",
+                "sum_kernel_us_per_step": sum(s["avg_us"] for s in stats),
+                "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
+                                  "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
+                                  "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)}
+                              for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["us"])}}
+
+    out = {
+        "metric": "head crops/sec (224x224)", "value": value, "unit": "crops/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"batch={B}/GPU 224x224 uint8 crops resident in HBM -> angles+argmax+logits "
+                               f"(BASELINE.json configs[{2 if world == 1 else 3}])",
+                   "batch_per_gpu": B, "global_batch": B * world, "weights": "synthetic random-init seed 1234",
+                   "parallelism": f"batch-shard x{world}, no data-path collective",
+                   "graph": not args.no_graph},
+        "roofline": roofline,
+        "path_fraction": {"per_gpu_crops_s": value / world,
+                          "vs_layer_granular_bound": value / world / PATH_BOUND_CROPS_S["layer_granular"],
+                          "vs_2kernel_fusion_bound": value / world / PATH_BOUND_CROPS_S["mbconv_2kernel_fusion"],
+                          "bounds_crops_s": PATH_BOUND_CROPS_S},
+    }
+
+    if rank == 0 and world == 1:
+        # correctness spot check against the float64 oracle (outside every timed region)
+        from oracle import whenet_oracle as O
+        ref = O.forward(crops[:2], W.synthetic(1234), np.float64)
+        ref_ang = np.stack([ref["yaw"], ref["pitch"], ref["roll"]], axis=1)
+        got = d_ypr.cpu().numpy()[:2]
+        out["check"] = {"max_abs_deg_vs_f64_oracle": float(np.abs(got - ref_ang).max()), "crops": 2}
+        # configs[1]: batch=1 fp32 latency
+        h1 = _lib.Handle(blob, device=local_rank, dtype=_lib.F32)
+        lat = []
+        for i in range(1100):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            h1.forward_device(d_crops.data_ptr(), 1, d_ypr.data_ptr(), d_am.data_ptr(), d_lg.data_ptr())
+            h1.sync()
+            lat.append(time.perf_counter() - a)
+        lat = np.array(lat[100:]) * 1e6
+        out["latency_b1"] = {"dtype": "f32", "median_us": float(np.median(lat)), "p99_us": float(np.percentile(lat, 99)),
+                             "iters": 1000, "crops_per_s": float(1e6 / np.median(lat))}
+        h1.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    h.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

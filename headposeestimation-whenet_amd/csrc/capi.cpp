@@ -1,0 +1,225 @@
+// extern "C" surface of libwhenet_hip.so (include/whenet_hip.h).  Every entry point catches
+// everything: no exception crosses the ABI.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <vector>
+
+#include "engine.h"
+
+struct whenet_ctx {
+    whenet::Engine* engine = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename F>
+int guarded(whenet_t* h, F&& fn) {
+    if (h == nullptr || h->engine == nullptr) return WHENET_EINVAL;
+    try {
+        fn(*h->engine);
+        return WHENET_OK;
+    } catch (const whenet::Error& e) {
+        h->engine->last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        h->engine->last_error = "out of host memory";
+        return WHENET_ENOMEM;
+    } catch (const std::exception& e) {
+        h->engine->last_error = e.what();
+        return WHENET_EHIP;
+    } catch (...) {
+        h->engine->last_error = "unknown error";
+        return WHENET_EHIP;
+    }
+}
+
+int create_impl(const void* blob, size_t nbytes, int device_id, int dtype, whenet_t** out) {
+    if (out == nullptr) return WHENET_EINVAL;
+    *out = nullptr;
+    try {
+        std::unique_ptr<whenet::Engine> e(new whenet::Engine(blob, nbytes, device_id, dtype));
+        whenet_t* h = new whenet_t;
+        h->engine = e.release();
+        *out = h;
+        return WHENET_OK;
+    } catch (const whenet::Error& e) {
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_create_error = "out of host memory";
+        return WHENET_ENOMEM;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return WHENET_EHIP;
+    } catch (...) {
+        g_create_error = "unknown error";
+        return WHENET_EHIP;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int whenet_create(const char* snapshot_path, int device_id, int dtype, whenet_t** out) {
+    if (snapshot_path == nullptr || out == nullptr) {
+        g_create_error = "whenet_create: NULL argument";
+        return WHENET_EINVAL;
+    }
+    std::vector<char> blob;
+    try {
+        std::ifstream f(snapshot_path, std::ios::binary | std::ios::ate);
+        if (!f) {
+            g_create_error = std::string("cannot open snapshot '") + snapshot_path + "'";
+            return WHENET_ENOENT;
+        }
+        const std::streamsize sz = f.tellg();
+        f.seekg(0);
+        blob.resize(size_t(sz));
+        if (sz > 0 && !f.read(blob.data(), sz)) {
+            g_create_error = std::string("cannot read snapshot '") + snapshot_path + "'";
+            return WHENET_EIO;
+        }
+    } catch (const std::bad_alloc&) {
+        g_create_error = "out of host memory";
+        return WHENET_ENOMEM;
+    }
+    return create_impl(blob.data(), blob.size(), device_id, dtype, out);
+}
+
+int whenet_create_from_memory(const void* snapshot, size_t nbytes, int device_id, int dtype, whenet_t** out) {
+    if (snapshot == nullptr || out == nullptr) {
+        g_create_error = "whenet_create_from_memory: NULL argument";
+        return WHENET_EINVAL;
+    }
+    return create_impl(snapshot, nbytes, device_id, dtype, out);
+}
+
+void whenet_destroy(whenet_t* h) {
+    if (h == nullptr) return;
+    try {
+        delete h->engine;
+    } catch (...) {
+    }
+    delete h;
+}
+
+const char* whenet_last_error(const whenet_t* h) {
+    if (h == nullptr || h->engine == nullptr) return g_create_error.c_str();
+    return h->engine->last_error.c_str();
+}
+
+int whenet_get_info(const whenet_t* h, whenet_info_t* out) {
+    if (h == nullptr || h->engine == nullptr || out == nullptr) return WHENET_EINVAL;
+    h->engine->get_info(out);
+    return WHENET_OK;
+}
+
+int whenet_set_option(whenet_t* h, const char* key, long value) {
+    if (key == nullptr) return WHENET_EINVAL;
+    return guarded(h, [&](whenet::Engine& e) { e.set_option(key, value); });
+}
+
+int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits) {
+    return guarded(h, [&](whenet::Engine& e) { e.forward_host(crops, n, ypr, argmax, logits); });
+}
+
+int whenet_forward_u8_device(whenet_t* h, const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax,
+                             float* d_logits, void* stream) {
+    return guarded(h, [&](whenet::Engine& e) {
+        e.forward_device(d_crops, n, d_ypr, d_argmax, d_logits, static_cast<hipStream_t>(stream));
+    });
+}
+
+int whenet_sync(whenet_t* h) {
+    return guarded(h, [&](whenet::Engine& e) { e.sync(); });
+}
+
+int whenet_submit_u8(whenet_t* h, const uint8_t* crops, int n, int* ticket) {
+    if (ticket == nullptr) return WHENET_EINVAL;
+    return guarded(h, [&](whenet::Engine& e) { *ticket = e.submit(crops, n); });
+}
+
+int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits) {
+    return guarded(h, [&](whenet::Engine& e) { e.collect(ticket, ypr, argmax, logits); });
+}
+
+int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap,
+                   int* count) {
+    return guarded(h, [&](whenet::Engine& e) {
+        const int c = e.profile(d_crops, n, iters, stats, cap);
+        if (count) *count = c;
+    });
+}
+
+int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* out) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_stem(crops, n, out); });
+}
+
+int whenet_op_block(whenet_t* h, int index, const float* in, int n, float* expand_out, float* dw_out, float* gate,
+                    float* out) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_block(index, in, n, expand_out, dw_out, gate, out); });
+}
+
+int whenet_op_head(whenet_t* h, const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_head(in, n, feat, logits, ypr, argmax); });
+}
+
+int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_decode(logits, n, ypr, argmax); });
+}
+
+int whenet_block_spec(int index, int32_t out[8]) {
+    if (out == nullptr) return WHENET_EINVAL;
+    try {
+        const auto blocks = whenet::make_blocks();
+        if (index < 1 || index > int(blocks.size())) return WHENET_EINVAL;
+        const whenet::BlockSpec& b = blocks[size_t(index - 1)];
+        const int32_t v[8] = {b.k, b.s, b.expand, b.cin, b.cout, b.h_in, b.h_out, b.se_reduced()};
+        std::memcpy(out, v, sizeof(v));
+        return WHENET_OK;
+    } catch (...) {
+        return WHENET_ENOMEM;
+    }
+}
+
+int whenet_dw_plan(int dtype, int index, int32_t out[12]) {
+    if (out == nullptr || (dtype != WHENET_F32 && dtype != WHENET_F16)) return WHENET_EINVAL;
+    try {
+        const auto blocks = whenet::make_blocks();
+        if (index < 1 || index > int(blocks.size())) return WHENET_EINVAL;
+        const whenet::BlockSpec& b = blocks[size_t(index - 1)];
+        const whenet::DwPlan p = whenet::plan_dw(dtype, b.k, b.s, b.h_in, b.h_out, b.cexp());
+        const int32_t v[12] = {p.threads, p.CV, p.TH, p.NSX, p.tiles_x, p.tiles_y, p.chunks, p.IH, p.IW,
+                               int32_t(p.lds_bytes), b.pad_before(), b.cexp()};
+        std::memcpy(out, v, sizeof(v));
+        return WHENET_OK;
+    } catch (...) {
+        return WHENET_EINVAL;
+    }
+}
+
+int whenet_device_alloc(whenet_t* h, size_t nbytes, void** d_ptr) {
+    if (d_ptr == nullptr) return WHENET_EINVAL;
+    return guarded(h, [&](whenet::Engine& e) { *d_ptr = e.dev_alloc(nbytes); });
+}
+
+int whenet_device_free(whenet_t* h, void* d_ptr) {
+    return guarded(h, [&](whenet::Engine& e) { e.dev_free(d_ptr); });
+}
+
+int whenet_memcpy_h2d(whenet_t* h, void* d_dst, const void* src, size_t nbytes) {
+    return guarded(h, [&](whenet::Engine& e) { e.h2d(d_dst, src, nbytes); });
+}
+
+int whenet_memcpy_d2h(whenet_t* h, void* dst, const void* d_src, size_t nbytes) {
+    return guarded(h, [&](whenet::Engine& e) { e.d2h(dst, d_src, nbytes); });
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,706 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace whenet {
+
+namespace {
+
+constexpr size_t X_ELEMS = size_t(112) * 112 * 32;    // largest block input/output per crop (stem out)
+constexpr size_t E_ELEMS = size_t(112) * 112 * 96;    // largest expanded tensor per crop (b2 expand)
+constexpr size_t D_ELEMS = size_t(56) * 56 * 144;     // largest depthwise output per crop (b3 dw)
+constexpr size_t HC_ELEMS = size_t(49) * FEAT;        // head conv output per crop
+constexpr size_t IN_BYTES = size_t(IMG) * IMG * 3;
+constexpr int MAX_GRAPHS = 16;
+
+struct DeviceGuard {
+    explicit DeviceGuard(int dev) { WHENET_HIP_CHECK(hipSetDevice(dev)); }
+};
+
+struct TempBufs {     // hipMalloc'd scratch of the single-stage entry points
+    std::vector<void*> ptrs;
+    void* get(size_t nbytes) {
+        void* p = nullptr;
+        WHENET_HIP_CHECK(hipMalloc(&p, nbytes ? nbytes : 16));
+        ptrs.push_back(p);
+        return p;
+    }
+    ~TempBufs() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+void copy_name(char* dst, size_t cap, const std::string& s) {
+    std::memset(dst, 0, cap);
+    std::memcpy(dst, s.data(), std::min(cap - 1, s.size()));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// construction / weights
+// ------------------------------------------------------------------------------------------
+void* Engine::upload_bytes(const void* p, size_t nbytes) {
+    void* d = nullptr;
+    WHENET_HIP_CHECK(hipMalloc(&d, nbytes ? nbytes : 16));
+    weight_allocs_.push_back(d);
+    if (nbytes) WHENET_HIP_CHECK(hipMemcpy(d, p, nbytes, hipMemcpyHostToDevice));
+    return d;
+}
+
+template <typename T> T* Engine::upload(const std::vector<T>& v) {
+    return static_cast<T*>(upload_bytes(v.data(), v.size() * sizeof(T)));
+}
+
+DevPw Engine::upload_pw(const HostPw& h) {
+    DevPw d;
+    d.K = h.K;
+    d.N = h.N;
+    d.KS = h.KS;
+    d.NTILES = h.NTILES;
+    d.wp = upload_bytes(h.packed.data(), h.packed.size());
+    d.wdense = upload(h.dense);
+    d.bias = upload(h.bias);
+    return d;
+}
+
+Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : device_(device_id), dtype_(dtype) {
+    // host-side preparation first: a malformed snapshot is reported as such even on a box
+    // without a GPU
+    HostModel m = build_host_model(parse_snapshot(snapshot, nbytes), dtype);
+    params_backbone_ = m.params_backbone;
+    params_heads_ = m.params_heads;
+    n_tensors_ = m.n_tensors;
+
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw Error(WHENET_ENODEV, std::string("no HIP device visible (") + hipGetErrorString(e) +
+                                       "); libwhenet_hip has no CPU fallback");
+    WHENET_REQUIRE(device_id >= 0 && device_id < count, WHENET_ENODEV,
+                   "device_id " + std::to_string(device_id) + " out of range (" + std::to_string(count) + " devices)");
+    DeviceGuard guard(device_);
+    WHENET_HIP_CHECK(hipGetDeviceProperties(&prop_, device_));
+    WHENET_REQUIRE(std::strstr(prop_.gcnArchName, "gfx950") != nullptr, WHENET_ENODEV,
+                   std::string("device is ") + prop_.gcnArchName + "; this library carries gfx950 code only");
+    num_cus_ = prop_.multiProcessorCount;
+
+    WHENET_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    WHENET_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+
+    d_lut_ = static_cast<float*>(upload_bytes(&m.lut[0][0], sizeof(m.lut)));
+    d_stem_w_ = upload(m.stem_w);
+    d_stem_b_ = upload(m.stem_b);
+    for (const HostBlock& hb : m.blocks) {
+        DevBlock b;
+        b.spec = hb.spec;
+        if (hb.spec.has_expand()) b.expand = upload_pw(hb.expand);
+        b.dw.k = hb.dw.k;
+        b.dw.C = hb.dw.C;
+        b.dw.w = upload(hb.dw.w);
+        b.dw.bias = upload(hb.dw.bias);
+        b.dw.plan = plan_dw(dtype_, hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C);
+        b.se.C = hb.se.C;
+        b.se.R = hb.se.R;
+        b.se.w1t = upload(hb.se.w1t);
+        b.se.b1 = upload(hb.se.b1);
+        b.se.w2 = upload(hb.se.w2);
+        b.se.b2 = upload(hb.se.b2);
+        b.project = upload_pw(hb.project);
+        partial_per_crop_ = std::max(partial_per_crop_, size_t(b.dw.plan.ntiles()) * b.dw.C);
+        blocks_.push_back(b);
+    }
+    head_ = upload_pw(m.head);
+    d_dense_w_ = upload(m.dense_w);
+    d_dense_b_ = upload(m.dense_b);
+    WHENET_HIP_CHECK(hipDeviceSynchronize());
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+    graphs_.clear();
+    for (Slot& s : slots_) {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_ypr) (void)hipHostFree(s.h_ypr);
+        if (s.h_amax) (void)hipHostFree(s.h_amax);
+        if (s.h_logits) (void)hipHostFree(s.h_logits);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_ypr) (void)hipFree(s.d_ypr);
+        if (s.d_amax) (void)hipFree(s.d_amax);
+        if (s.d_logits) (void)hipFree(s.d_logits);
+        if (s.copied) (void)hipEventDestroy(s.copied);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, in_u8_, o_ypr_, o_amax_, o_logits_};
+    for (void* p : arena)
+        if (p) (void)hipFree(p);
+    for (void* p : weight_allocs_) (void)hipFree(p);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+}
+
+void Engine::set_option(const std::string& key, long value) {
+    DeviceGuard guard(device_);
+    if (key == "graph") {
+        use_graph_ = value != 0;
+    } else if (key == "pw_impl") {
+        WHENET_REQUIRE(value == 0 || value == 1, WHENET_EINVAL, "pw_impl must be 0 (MFMA) or 1 (check kernel)");
+        pw_impl_ = int(value);
+        sync();
+        drop_graphs();
+    } else {
+        throw Error(WHENET_EINVAL, "unknown option '" + key + "'");
+    }
+}
+
+void Engine::get_info(whenet_info_t* out) const {
+    std::memset(out, 0, sizeof(*out));
+    out->abi_version = WHENET_ABI_VERSION;
+    out->dtype = dtype_;
+    out->device_id = device_;
+    out->compute_units = num_cus_;
+    out->params_backbone = params_backbone_;
+    out->params_heads = params_heads_;
+    out->n_tensors = n_tensors_;
+    out->n_kernels_per_forward = 66;
+    out->macs_per_crop = 384857312;
+    out->arena_bytes = int64_t(arena_bytes_);
+    out->capacity = cap_;
+    out->graph_enabled = use_graph_ ? 1 : 0;
+    copy_name(out->device_name, sizeof(out->device_name), prop_.name);
+    copy_name(out->arch, sizeof(out->arch), prop_.gcnArchName);
+}
+
+// ------------------------------------------------------------------------------------------
+// arena
+// ------------------------------------------------------------------------------------------
+void Engine::drop_graphs() {
+    for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+    graphs_.clear();
+}
+
+void Engine::release_arena() {
+    void** arena[] = {&x0_, &x1_, &e_, &d_, &hc_, reinterpret_cast<void**>(&partial_), reinterpret_cast<void**>(&gate_),
+                      reinterpret_cast<void**>(&in_u8_), reinterpret_cast<void**>(&o_ypr_),
+                      reinterpret_cast<void**>(&o_amax_), reinterpret_cast<void**>(&o_logits_)};
+    for (void** p : arena) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    cap_ = 0;
+    arena_bytes_ = 0;
+}
+
+void Engine::ensure_capacity(int n) {
+    WHENET_REQUIRE(n >= 1, WHENET_EINVAL, "n must be >= 1");
+    if (n <= cap_) return;
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    drop_graphs();
+    release_arena();
+    const size_t N = size_t(n), es = esz();
+    size_t total = 0;
+    auto alloc = [&](size_t bytes) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            release_arena();
+            throw Error(WHENET_ENOMEM, "activation arena for n=" + std::to_string(n) + ": " + hipGetErrorString(e));
+        }
+        total += bytes;
+        return p;
+    };
+    x0_ = alloc(N * X_ELEMS * es);
+    x1_ = alloc(N * X_ELEMS * es);
+    e_ = alloc(N * E_ELEMS * es);
+    d_ = alloc(N * D_ELEMS * es);
+    hc_ = alloc(N * HC_ELEMS * es);
+    partial_ = static_cast<float*>(alloc(N * partial_per_crop_ * sizeof(float)));
+    gate_ = static_cast<float*>(alloc(N * 1152 * sizeof(float)));
+    in_u8_ = static_cast<uint8_t*>(alloc(N * IN_BYTES));
+    o_ypr_ = static_cast<float*>(alloc(N * 3 * sizeof(float)));
+    o_amax_ = static_cast<int32_t*>(alloc(N * 3 * sizeof(int32_t)));
+    o_logits_ = static_cast<float*>(alloc(N * N_LOGITS * sizeof(float)));
+    cap_ = n;
+    arena_bytes_ = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// the launch schedule
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Rec {
+    LaunchRecorder* rec;
+    hipStream_t s;
+    template <typename F>
+    void operator()(const std::string& layer, const char* kind, const char* kernel, double bytes, double flops, F&& fn) {
+        if (!rec) {
+            fn();
+            return;
+        }
+        if (rec->first_pass) {
+            LaunchRecorder::Entry e;
+            e.layer = layer;
+            e.kind = kind;
+            e.kernel = kernel;
+            e.bytes = bytes;
+            e.flops = flops;
+            WHENET_HIP_CHECK(hipEventCreate(&e.start));
+            WHENET_HIP_CHECK(hipEventCreate(&e.stop));
+            rec->entries.push_back(e);
+        }
+        LaunchRecorder::Entry& e = rec->entries.at(rec->cursor++);
+        WHENET_HIP_CHECK(hipEventRecord(e.start, s));
+        fn();
+        WHENET_HIP_CHECK(hipEventRecord(e.stop, s));
+    }
+};
+
+}  // namespace
+
+void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, hipStream_t s, LaunchRecorder* rec) {
+    Rec R{rec, s};
+    const BlockSpec& sp = b.spec;
+    const std::string p = "b" + std::to_string(sp.index);
+    const double es = double(esz());
+    const int hw_in = sp.h_in * sp.h_in, hw_out = sp.h_out * sp.h_out;
+    const int cexp = sp.cexp();
+    const void* dw_in = in;
+    if (sp.has_expand()) {
+        PwArgs a{};
+        a.a = in;
+        a.wp = b.expand.wp;
+        a.wdense = b.expand.wdense;
+        a.bias = b.expand.bias;
+        a.out = e_;
+        a.M = n * hw_in;
+        a.K = b.expand.K;
+        a.N = b.expand.N;
+        a.KS = b.expand.KS;
+        a.NTILES = b.expand.NTILES;
+        a.HW = hw_in;
+        a.act = ACT_SWISH;
+        R(p + "/expand", "pw", kernel_name_pw(dtype_, pw_impl_, false, false, ACT_SWISH), double(a.M) * (a.K + a.N) * es,
+          2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
+        dw_in = e_;
+    }
+    {
+        DwArgs a{};
+        a.in = dw_in;
+        a.out = d_;
+        a.w = b.dw.w;
+        a.bias = b.dw.bias;
+        a.partial = partial_;
+        a.k = sp.k;
+        a.s = sp.s;
+        a.H = sp.h_in;
+        a.Ho = sp.h_out;
+        a.C = cexp;
+        a.pad = sp.pad_before();
+        a.n = n;
+        a.plan = b.dw.plan;
+        R(p + "/dw", "dw", kernel_name_dw(dtype_, sp.k, sp.s), double(n) * (hw_in + hw_out) * cexp * es,
+          2.0 * n * hw_out * sp.k * sp.k * cexp, [&] { launch_dw(a, dtype_, s); });
+    }
+    {
+        SeArgs a{};
+        a.partial = partial_;
+        a.ntiles = b.dw.plan.ntiles();
+        a.inv_hw = 1.0f / float(hw_out);
+        a.w1t = b.se.w1t;
+        a.b1 = b.se.b1;
+        a.w2 = b.se.w2;
+        a.b2 = b.se.b2;
+        a.gate = gate_;
+        a.C = b.se.C;
+        a.R = b.se.R;
+        a.n = n;
+        R(p + "/se", "se", "whenet_se_kernel", double(n) * (a.ntiles + 1) * a.C * 4.0 + 2.0 * a.C * a.R * 4.0,
+          4.0 * n * a.C * a.R, [&] { launch_se(a, s); });
+    }
+    {
+        PwArgs a{};
+        a.a = d_;
+        a.wp = b.project.wp;
+        a.wdense = b.project.wdense;
+        a.bias = b.project.bias;
+        a.gate = gate_;
+        a.res = sp.has_skip() ? in : nullptr;
+        a.out = out;
+        a.M = n * hw_out;
+        a.K = b.project.K;
+        a.N = b.project.N;
+        a.KS = b.project.KS;
+        a.NTILES = b.project.NTILES;
+        a.HW = hw_out;
+        a.act = ACT_NONE;
+        R(p + "/project", "pw", kernel_name_pw(dtype_, pw_impl_, true, sp.has_skip(), ACT_NONE),
+          double(a.M) * (a.K + a.N + (sp.has_skip() ? a.N : 0)) * es, 2.0 * a.M * a.K * a.N,
+          [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
+    }
+}
+
+void Engine::enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
+                             LaunchRecorder* rec) {
+    Rec R{rec, s};
+    const double es = double(esz());
+    {
+        StemArgs a{d_in, x0_, d_stem_w_, d_stem_b_, d_lut_, n};
+        R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
+          [&] { launch_stem(a, dtype_, s); });
+    }
+    void* cur = x0_;
+    for (const DevBlock& b : blocks_) {
+        void* nxt = (cur == x0_) ? x1_ : x0_;
+        enqueue_block(b, cur, nxt, n, s, rec);
+        cur = nxt;
+    }
+    {
+        PwArgs a{};
+        a.a = cur;
+        a.wp = head_.wp;
+        a.wdense = head_.wdense;
+        a.bias = head_.bias;
+        a.out = hc_;
+        a.M = n * 49;
+        a.K = head_.K;
+        a.N = head_.N;
+        a.KS = head_.KS;
+        a.NTILES = head_.NTILES;
+        a.HW = 49;
+        a.act = ACT_SWISH;
+        R("head", "pw", kernel_name_pw(dtype_, pw_impl_, false, false, ACT_SWISH), double(a.M) * (a.K + a.N) * es,
+          2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
+    }
+    {
+        HeadsArgs a{};
+        a.x = hc_;
+        a.w = d_dense_w_;
+        a.b = d_dense_b_;
+        a.logits = d_logits;
+        a.ypr = d_ypr;
+        a.argmax = d_amax;
+        a.n = n;
+        R("heads", "heads", dtype_ == WHENET_F16 ? "whenet_heads_kernel<_Float16>" : "whenet_heads_kernel<float>",
+          double(n) * (HC_ELEMS * es + (N_LOGITS + 6) * 4.0) + double(FEAT) * N_LOGITS * 4.0, 2.0 * n * FEAT * N_LOGITS,
+          [&] { launch_heads(a, dtype_, s); });
+    }
+}
+
+void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
+    if (!use_graph_) {
+        enqueue_forward(d_in, n, d_ypr, d_amax, d_logits, s, nullptr);
+        return;
+    }
+    GraphKey key{n, d_in, d_ypr, d_amax, d_logits};
+    auto it = graphs_.find(key);
+    if (it == graphs_.end()) {
+        if (graphs_.size() >= size_t(MAX_GRAPHS)) {
+            WHENET_HIP_CHECK(hipStreamSynchronize(s));
+            drop_graphs();
+        }
+        hipGraph_t graph = nullptr;
+        WHENET_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        try {
+            enqueue_forward(d_in, n, d_ypr, d_amax, d_logits, s, nullptr);
+        } catch (...) {
+            (void)hipStreamEndCapture(s, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        WHENET_HIP_CHECK(hipStreamEndCapture(s, &graph));
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) throw Error(WHENET_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        it = graphs_.emplace(key, exec).first;
+    }
+    WHENET_HIP_CHECK(hipGraphLaunch(it->second, s));
+}
+
+// ------------------------------------------------------------------------------------------
+// public paths
+// ------------------------------------------------------------------------------------------
+void Engine::forward_device(const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax, float* d_logits,
+                            hipStream_t stream) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(d_crops != nullptr && d_ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
+    WHENET_REQUIRE((reinterpret_cast<uintptr_t>(d_crops) & 3) == 0, WHENET_EINVAL, "crops must be 4-byte aligned");
+    ensure_capacity(n);
+    run_forward(d_crops, n, d_ypr, d_argmax, d_logits, stream ? stream : stream_);
+}
+
+void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(crops != nullptr && ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
+    ensure_capacity(n);
+    const size_t N = size_t(n);
+    WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
+    run_forward(in_u8_, n, o_ypr_, o_amax_, o_logits_, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    if (logits)
+        WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::sync() {
+    DeviceGuard guard(device_);
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(copy_stream_));
+}
+
+void Engine::ensure_slot(Slot& s, int n) {
+    if (!s.copied) {
+        WHENET_HIP_CHECK(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        WHENET_HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    if (n <= s.capacity) return;
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_ypr) (void)hipHostFree(s.h_ypr);
+    if (s.h_amax) (void)hipHostFree(s.h_amax);
+    if (s.h_logits) (void)hipHostFree(s.h_logits);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_ypr) (void)hipFree(s.d_ypr);
+    if (s.d_amax) (void)hipFree(s.d_amax);
+    if (s.d_logits) (void)hipFree(s.d_logits);
+    s.h_in = nullptr; s.h_ypr = nullptr; s.h_amax = nullptr; s.h_logits = nullptr;
+    s.d_in = nullptr; s.d_ypr = nullptr; s.d_amax = nullptr; s.d_logits = nullptr;
+    s.capacity = 0;
+    const size_t N = size_t(n);
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_in), N * IN_BYTES, hipHostMallocDefault));
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_ypr), N * 3 * sizeof(float), hipHostMallocDefault));
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_amax), N * 3 * sizeof(int32_t), hipHostMallocDefault));
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_logits), N * N_LOGITS * sizeof(float), hipHostMallocDefault));
+    WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_in), N * IN_BYTES));
+    WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_ypr), N * 3 * sizeof(float)));
+    WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_amax), N * 3 * sizeof(int32_t)));
+    WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_logits), N * N_LOGITS * sizeof(float)));
+    s.capacity = n;
+}
+
+int Engine::submit(const uint8_t* crops, int n) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(crops != nullptr, WHENET_EINVAL, "crops must not be NULL");
+    Slot* slot = nullptr;
+    for (Slot& s : slots_)
+        if (!s.busy) {
+            slot = &s;
+            break;
+        }
+    WHENET_REQUIRE(slot != nullptr, WHENET_EINVAL, "too many submissions in flight (collect one first)");
+    ensure_capacity(n);
+    ensure_slot(*slot, n);
+    const size_t N = size_t(n);
+    std::memcpy(slot->h_in, crops, N * IN_BYTES);
+    WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream_));
+    WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream_));
+    WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
+    run_forward(slot->d_in, n, slot->d_ypr, slot->d_amax, slot->d_logits, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_ypr, slot->d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_amax, slot->d_amax, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_logits, slot->d_logits, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipEventRecord(slot->done, stream_));
+    slot->busy = true;
+    slot->n = n;
+    slot->ticket = next_ticket_++;
+    return slot->ticket;
+}
+
+void Engine::collect(int ticket, float* ypr, int32_t* argmax, float* logits) {
+    DeviceGuard guard(device_);
+    Slot* slot = nullptr;
+    for (Slot& s : slots_)
+        if (s.busy && s.ticket == ticket) slot = &s;
+    WHENET_REQUIRE(slot != nullptr, WHENET_EINVAL, "unknown or already collected ticket " + std::to_string(ticket));
+    WHENET_HIP_CHECK(hipEventSynchronize(slot->done));
+    const size_t N = size_t(slot->n);
+    if (ypr) std::memcpy(ypr, slot->h_ypr, N * 3 * sizeof(float));
+    if (argmax) std::memcpy(argmax, slot->h_amax, N * 3 * sizeof(int32_t));
+    if (logits) std::memcpy(logits, slot->h_logits, N * N_LOGITS * sizeof(float));
+    slot->busy = false;
+}
+
+int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(d_crops != nullptr && iters >= 1, WHENET_EINVAL, "profile: bad arguments");
+    ensure_capacity(n);
+    LaunchRecorder rec;
+    struct Cleanup {
+        LaunchRecorder& r;
+        ~Cleanup() {
+            for (auto& e : r.entries) {
+                if (e.start) (void)hipEventDestroy(e.start);
+                if (e.stop) (void)hipEventDestroy(e.stop);
+            }
+        }
+    } cleanup{rec};
+    // one untimed eager pass so that lazy code-object loading does not land in the numbers
+    enqueue_forward(d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, nullptr);
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int it = 0; it < iters; ++it) {
+        rec.cursor = 0;
+        enqueue_forward(d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, &rec);
+        rec.first_pass = false;
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+        for (auto& e : rec.entries) {
+            float ms = 0.f;
+            WHENET_HIP_CHECK(hipEventElapsedTime(&ms, e.start, e.stop));
+            e.total_ms += ms;
+        }
+    }
+    const int count = int(rec.entries.size());
+    for (int i = 0; i < count && i < cap && stats; ++i) {
+        const auto& e = rec.entries[size_t(i)];
+        whenet_launch_stat_t& o = stats[i];
+        copy_name(o.layer, sizeof(o.layer), e.layer);
+        copy_name(o.kind, sizeof(o.kind), e.kind);
+        copy_name(o.kernel, sizeof(o.kernel), e.kernel);
+        o.avg_us = e.total_ms * 1000.0 / iters;
+        o.alg_bytes = e.bytes;
+        o.alg_flops = e.flops;
+    }
+    return count;
+}
+
+// ------------------------------------------------------------------------------------------
+// single-stage entry points (tests)
+// ------------------------------------------------------------------------------------------
+void Engine::op_stem(const uint8_t* crops, int n, float* out) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(crops && out, WHENET_EINVAL, "op_stem: NULL argument");
+    ensure_capacity(n);
+    TempBufs tmp;
+    const size_t N = size_t(n);
+    float* d_out = static_cast<float*>(tmp.get(N * X_ELEMS * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
+    StemArgs a{in_u8_, x0_, d_stem_w_, d_stem_b_, d_lut_, n};
+    launch_stem(a, dtype_, stream_);
+    launch_act_to_f32(x0_, d_out, N * X_ELEMS, dtype_, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(out, d_out, N * X_ELEMS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(index >= 1 && index <= int(blocks_.size()), WHENET_EINVAL, "op_block: index must be 1..16");
+    WHENET_REQUIRE(in != nullptr, WHENET_EINVAL, "op_block: NULL input");
+    ensure_capacity(n);
+    const DevBlock& b = blocks_[size_t(index - 1)];
+    const BlockSpec& sp = b.spec;
+    const size_t N = size_t(n);
+    const size_t in_elems = N * sp.h_in * sp.h_in * sp.cin;
+    const size_t exp_elems = N * sp.h_in * sp.h_in * sp.cexp();
+    const size_t dw_elems = N * sp.h_out * sp.h_out * sp.cexp();
+    const size_t out_elems = N * sp.h_out * sp.h_out * sp.cout;
+    TempBufs tmp;
+    float* d_f32 = static_cast<float*>(tmp.get(std::max({in_elems, exp_elems, dw_elems, out_elems}) * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
+    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
+    enqueue_block(b, x0_, x1_, n, stream_, nullptr);
+    auto fetch = [&](const void* src, size_t elems, float* dst) {
+        if (!dst) return;
+        launch_act_to_f32(src, d_f32, elems, dtype_, stream_);
+        WHENET_HIP_CHECK(hipMemcpyAsync(dst, d_f32, elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    };
+    if (sp.has_expand()) fetch(e_, exp_elems, expand_out);
+    fetch(d_, dw_elems, dw_out);
+    if (gate) {
+        WHENET_HIP_CHECK(hipMemcpyAsync(gate, gate_, N * sp.cexp() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    fetch(x1_, out_elems, out);
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(in != nullptr, WHENET_EINVAL, "op_head: NULL input");
+    ensure_capacity(n);
+    const size_t N = size_t(n);
+    const size_t in_elems = N * 49 * 320;
+    TempBufs tmp;
+    float* d_f32 = static_cast<float*>(tmp.get(in_elems * sizeof(float)));
+    float* d_feat = static_cast<float*>(tmp.get(N * FEAT * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
+    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
+    PwArgs a{};
+    a.a = x0_;
+    a.wp = head_.wp;
+    a.wdense = head_.wdense;
+    a.bias = head_.bias;
+    a.out = hc_;
+    a.M = n * 49;
+    a.K = head_.K;
+    a.N = head_.N;
+    a.KS = head_.KS;
+    a.NTILES = head_.NTILES;
+    a.HW = 49;
+    a.act = ACT_SWISH;
+    launch_pw(a, dtype_, pw_impl_, num_cus_, stream_);
+    HeadsArgs h{};
+    h.x = hc_;
+    h.w = d_dense_w_;
+    h.b = d_dense_b_;
+    h.feat = d_feat;
+    h.logits = o_logits_;
+    h.ypr = o_ypr_;
+    h.argmax = o_amax_;
+    h.n = n;
+    launch_heads(h, dtype_, stream_);
+    if (feat) WHENET_HIP_CHECK(hipMemcpyAsync(feat, d_feat, N * FEAT * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (logits) WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (ypr) WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_decode(const float* logits, int n, float* ypr, int32_t* argmax) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(logits && ypr, WHENET_EINVAL, "op_decode: NULL argument");
+    ensure_capacity(n);
+    const size_t N = size_t(n);
+    TempBufs tmp;
+    float* d_lg = static_cast<float*>(tmp.get(N * N_LOGITS * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(d_lg, logits, N * N_LOGITS * sizeof(float), hipMemcpyHostToDevice, stream_));
+    HeadsArgs h{};
+    h.logits_in = d_lg;
+    h.w = d_dense_w_;
+    h.b = d_dense_b_;
+    h.ypr = o_ypr_;
+    h.argmax = o_amax_;
+    h.n = n;
+    launch_heads(h, WHENET_F32, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------------------------------
+void* Engine::dev_alloc(size_t nbytes) {
+    DeviceGuard guard(device_);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, nbytes ? nbytes : 16);
+    if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return p;
+}
+void Engine::dev_free(void* p) {
+    DeviceGuard guard(device_);
+    if (p) WHENET_HIP_CHECK(hipFree(p));
+}
+void Engine::h2d(void* d, const void* s, size_t nbytes) {
+    DeviceGuard guard(device_);
+    WHENET_HIP_CHECK(hipMemcpy(d, s, nbytes, hipMemcpyHostToDevice));
+}
+void Engine::d2h(void* d, const void* s, size_t nbytes) {
+    DeviceGuard guard(device_);
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    WHENET_HIP_CHECK(hipMemcpy(d, s, nbytes, hipMemcpyDeviceToHost));
+}
+
+}  // namespace whenet

@@ -1,0 +1,145 @@
+// The per-GPU inference engine behind the C ABI: device weights, activation arena, launch
+// schedule of the 66 kernels of one forward, hipGraph cache, per-launch profiling, and the
+// pinned-buffer submit/collect pipeline.  One engine = one device + one stream; not thread-safe.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "snapshot.h"
+
+namespace whenet {
+
+struct DevPw {
+    int K = 0, N = 0, KS = 0, NTILES = 0;
+    void* wp = nullptr;
+    float* wdense = nullptr;
+    float* bias = nullptr;
+};
+struct DevDw {
+    int k = 0, C = 0;
+    float* w = nullptr;
+    float* bias = nullptr;
+    DwPlan plan;
+};
+struct DevSe {
+    int C = 0, R = 0;
+    float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+struct DevBlock {
+    BlockSpec spec;
+    DevPw expand;
+    DevDw dw;
+    DevSe se;
+    DevPw project;
+};
+
+// Collects one entry per kernel launch when profiling (event pair around each launch).
+struct LaunchRecorder {
+    struct Entry {
+        std::string layer, kind, kernel;
+        double bytes = 0, flops = 0;
+        hipEvent_t start = nullptr, stop = nullptr;
+        double total_ms = 0;
+    };
+    std::vector<Entry> entries;
+    size_t cursor = 0;
+    bool first_pass = true;
+};
+
+class Engine {
+  public:
+    Engine(const void* snapshot, size_t nbytes, int device_id, int dtype);
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    void set_option(const std::string& key, long value);
+    void get_info(whenet_info_t* out) const;
+
+    void forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits);
+    void forward_device(const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax, float* d_logits,
+                        hipStream_t stream);
+    void sync();
+    int submit(const uint8_t* crops, int n);
+    void collect(int ticket, float* ypr, int32_t* argmax, float* logits);
+    int profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap);
+
+    void op_stem(const uint8_t* crops, int n, float* out);
+    void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
+    void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
+    void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
+
+    void* dev_alloc(size_t nbytes);
+    void dev_free(void* p);
+    void h2d(void* d, const void* s, size_t nbytes);
+    void d2h(void* d, const void* s, size_t nbytes);
+
+    std::string last_error;
+
+  private:
+    struct Slot {          // one in-flight submission of the pinned pipeline
+        int capacity = 0, n = 0, ticket = -1;
+        bool busy = false;
+        uint8_t* h_in = nullptr;
+        uint8_t* d_in = nullptr;
+        float *h_ypr = nullptr, *d_ypr = nullptr;
+        int32_t *h_amax = nullptr, *d_amax = nullptr;
+        float *h_logits = nullptr, *d_logits = nullptr;
+        hipEvent_t copied = nullptr, done = nullptr;
+    };
+
+    template <typename T> T* upload(const std::vector<T>& v);
+    void* upload_bytes(const void* p, size_t nbytes);
+    DevPw upload_pw(const HostPw& h);
+    void ensure_capacity(int n);
+    void release_arena();
+    void drop_graphs();
+    size_t esz() const { return dtype_ == WHENET_F16 ? 2 : 4; }
+
+    // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
+    void enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
+                         LaunchRecorder* rec);
+    void enqueue_block(const DevBlock& b, const void* in, void* out, int n, hipStream_t s, LaunchRecorder* rec);
+    void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
+    void ensure_slot(Slot& s, int n);
+
+    int device_ = 0, dtype_ = WHENET_F32, num_cus_ = 256;
+    bool use_graph_ = true;
+    int pw_impl_ = 0;
+    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
+    hipDeviceProp_t prop_{};
+    int64_t params_backbone_ = 0, params_heads_ = 0;
+    int n_tensors_ = 0;
+
+    // weights
+    std::vector<void*> weight_allocs_;
+    float *d_lut_ = nullptr, *d_stem_w_ = nullptr, *d_stem_b_ = nullptr;
+    std::vector<DevBlock> blocks_;
+    DevPw head_;
+    float *d_dense_w_ = nullptr, *d_dense_b_ = nullptr;
+
+    // activation arena (grown to the largest n seen)
+    int cap_ = 0;
+    size_t arena_bytes_ = 0;
+    void *x0_ = nullptr, *x1_ = nullptr, *e_ = nullptr, *d_ = nullptr, *hc_ = nullptr;
+    float *partial_ = nullptr, *gate_ = nullptr;
+    uint8_t* in_u8_ = nullptr;
+    float* o_ypr_ = nullptr;
+    int32_t* o_amax_ = nullptr;
+    float* o_logits_ = nullptr;
+    size_t partial_per_crop_ = 0;
+
+    using GraphKey = std::tuple<int, const void*, void*, void*, void*>;
+    std::map<GraphKey, hipGraphExec_t> graphs_;
+
+    Slot slots_[WHENET_MAX_INFLIGHT];
+    int next_ticket_ = 0;
+};
+
+}  // namespace whenet

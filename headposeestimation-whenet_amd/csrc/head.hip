@@ -1,0 +1,131 @@
+// GlobalAveragePooling2D + Dense(yaw 120 | pitch 66 | roll 66) + softmax-expectation decode.
+//
+// Reference: /root/reference/whenet.py:10 (GAP over the 7x7x1280 head-conv output),
+// whenet.py:11-13 (three linear Dense heads), utils.py:7-11 (softmax: subtract row max, exp,
+// divide by the sum) and whenet.py:28-33 (expectation over bin indices, *3 - 180 / - 99).
+// "Bin argmax" (north-star) = first index of the maximum logit, as np.argmax.
+//
+// One workgroup per crop, all f32: 0.1 % of the network's MACs; fused so the 1280 features and
+// the 252 logits never leave the CU.  Fixed reduction orders -> bitwise reproducible.
+#include "device_math.h"
+#include "kernels.h"
+
+namespace whenet {
+
+namespace {
+
+constexpr int HW = 49;
+
+template <typename T>
+__global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__ x, const float* __restrict__ feat_in,
+                                                           const float* __restrict__ logits_in,
+                                                           const float* __restrict__ w, const float* __restrict__ bvec,
+                                                           float* __restrict__ feat_out, float* __restrict__ logits_out,
+                                                           float* __restrict__ ypr, int32_t* __restrict__ amax) {
+    __shared__ float s_feat[FEAT];
+    __shared__ float s_part[4][N_LOGITS + 4];
+    __shared__ float s_logit[N_LOGITS + 4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+
+    if (logits_in == nullptr) {
+        // ---- GAP: mean over the 49 positions (whenet.py:10) -------------------------------
+        if (x != nullptr) {
+            const T* xb = x + size_t(b) * HW * FEAT;
+            for (int c = tid; c < FEAT; c += 256) {
+                float t = 0.0f;
+                for (int p = 0; p < HW; ++p) t += float(xb[size_t(p) * FEAT + c]);
+                s_feat[c] = t * (1.0f / 49.0f);
+            }
+        } else {
+            for (int c = tid; c < FEAT; c += 256) s_feat[c] = feat_in[size_t(b) * FEAT + c];
+        }
+        __syncthreads();
+        if (feat_out != nullptr)
+            for (int c = tid; c < FEAT; c += 256) feat_out[size_t(b) * FEAT + c] = s_feat[c];
+
+        // ---- Dense: logits[j] = sum_c feat[c]*W[c][j] + b[j]  (whenet.py:11-13) ------------
+        // 4 waves split the 1280-long contraction; lane j of each wave owns logits j, j+64, ...
+        const int wave = tid >> 6, lane = tid & 63;
+        const int c_lo = wave * (FEAT / 4), c_hi = c_lo + FEAT / 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float f = s_feat[c];
+            const float* wr = w + size_t(c) * N_LOGITS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = lane + 64 * i;
+                if (j < N_LOGITS) acc[i] = fmaf(f, wr[j], acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = lane + 64 * i;
+            if (j < N_LOGITS) s_part[wave][j] = acc[i];
+        }
+        __syncthreads();
+        if (tid < N_LOGITS) s_logit[tid] = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + bvec[tid];
+    } else {
+        if (tid < N_LOGITS) s_logit[tid] = logits_in[size_t(b) * N_LOGITS + tid];
+    }
+    __syncthreads();
+    if (logits_out != nullptr && tid < N_LOGITS) logits_out[size_t(b) * N_LOGITS + tid] = s_logit[tid];
+
+    // ---- decode: wave h handles head h (utils.py:7-11, whenet.py:28-33) --------------------
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave >= 3) return;
+    const int lo = (wave == 0) ? 0 : (wave == 1 ? N_YAW : N_YAW + N_PITCH);
+    const int nb = (wave == 0) ? N_YAW : N_PITCH;
+    // row max + first argmax
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = lane; j < nb; j += 64) {
+        const float v = s_logit[lo + j];
+        if (v > mx) { mx = v; mi = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(mx, off, 64);
+        const int oi = __shfl_xor(mi, off, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    // a = exp(x - max); b = sum(a); expectation = sum(a/b * idx)
+    float se = 0.0f;
+    float e[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = lane + 64 * i;
+        e[i] = (j < nb) ? expf(s_logit[lo + j] - mx) : 0.0f;
+        se += e[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+    float ex = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nb) ex += (e[i] / se) * float(j);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
+    if (lane == 0) {
+        ypr[size_t(b) * 3 + wave] = ex * 3.0f - ((wave == 0) ? 180.0f : 99.0f);
+        if (amax != nullptr) amax[size_t(b) * 3 + wave] = mi;
+    }
+}
+
+}  // namespace
+
+void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream) {
+    if (dtype == WHENET_F16 && a.x != nullptr)
+        hipLaunchKernelGGL(whenet_heads_kernel<half_t>, dim3(a.n), dim3(256), 0, stream,
+                           static_cast<const half_t*>(a.x), a.feat_in, a.logits_in, a.w, a.b, a.feat, a.logits, a.ypr,
+                           a.argmax);
+    else
+        hipLaunchKernelGGL(whenet_heads_kernel<float>, dim3(a.n), dim3(256), 0, stream,
+                           static_cast<const float*>(a.x), a.feat_in, a.logits_in, a.w, a.b, a.feat, a.logits, a.ypr,
+                           a.argmax);
+    WHENET_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace whenet

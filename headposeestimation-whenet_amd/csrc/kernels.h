@@ -1,0 +1,103 @@
+// Launchers of the hand-written gfx950 kernels.  Every launcher enqueues exactly one kernel
+// on `stream` and returns; `dtype` selects the float / _Float16 instantiation.
+#pragma once
+
+#include "common.h"
+
+namespace whenet {
+
+// ---- stem.hip ---------------------------------------------------------------------------
+// uint8 crops -> LUT normalise (whenet.py:23-26) -> Conv3x3/s2 'same' + BN + Swish.
+struct StemArgs {
+    const uint8_t* in;     // [n,224,224,3]
+    void* out;             // [n,112,112,32] T
+    const float* w;        // [27][32]
+    const float* bias;     // [32]
+    const float* lut;      // [3][256]
+    int n;
+};
+void launch_stem(const StemArgs& a, int dtype, hipStream_t stream);
+
+// ---- dw.hip -----------------------------------------------------------------------------
+// Depthwise kxk conv (TF 'same') + BN + Swish, NHWC, LDS-staged halo tiles, plus the
+// per-tile channel sums the squeeze-excite mean is built from.
+struct DwPlan {
+    int threads = 256;     // block size (128 for the stride-2 layers: 4x input footprint)
+    int CV = 1;            // 16-byte channel vectors per block
+    int TH = 1;            // output rows per block
+    int NSX = 1;           // 7-pixel output strips per tile row  (tile width = 7*NSX)
+    int tiles_x = 1, tiles_y = 1, chunks = 1;
+    int IH = 0, IW = 0;    // input tile (with halo)
+    size_t lds_bytes = 0;
+    int ntiles() const { return tiles_x * tiles_y; }
+};
+DwPlan plan_dw(int dtype, int k, int s, int H, int Ho, int C);
+
+struct DwArgs {
+    const void* in;        // [n,H,H,C] T
+    void* out;             // [n,Ho,Ho,C] T
+    const float* w;        // [k*k][C]
+    const float* bias;     // [C]
+    float* partial;        // [n][ntiles][C]  sums of the tile's outputs (pre-rounding f32)
+    int k, s, H, Ho, C, pad, n;
+    DwPlan plan;
+};
+void launch_dw(const DwArgs& a, int dtype, hipStream_t stream);
+
+// ---- se.hip -----------------------------------------------------------------------------
+// SEBlock: mean over H,W -> Conv1x1+bias -> Swish -> Conv1x1+bias -> sigmoid.
+struct SeArgs {
+    const float* partial;  // [n][ntiles][C]
+    int ntiles;
+    float inv_hw;
+    const float* w1t;      // [R][C]
+    const float* b1;       // [R]
+    const float* w2;       // [R][C]
+    const float* b2;       // [C]
+    float* gate;           // [n][C]
+    int C, R, n;
+};
+void launch_se(const SeArgs& a, hipStream_t stream);
+
+// ---- pw.hip -----------------------------------------------------------------------------
+// 1x1 convolution as an MFMA GEMM over M = n*H*W rows:
+//   out[m][:] = act( (a[m][:] * gate[m / HW][:]) @ W + bias ) (+ res[m][:])
+enum { ACT_NONE = 0, ACT_SWISH = 1 };
+struct PwArgs {
+    const void* a;         // [M][K] T
+    const void* wp;        // packed MFMA operand image (snapshot.h)
+    const float* wdense;   // [K][N] (check kernel only)
+    const float* bias;     // [N]
+    const float* gate;     // [n][K] or nullptr
+    const void* res;       // [M][N] T or nullptr
+    void* out;             // [M][N] T
+    int M, K, N, KS, NTILES, HW, act;
+};
+void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream);
+
+// ---- head.hip ---------------------------------------------------------------------------
+// GlobalAveragePooling2D + Dense(120|66|66) + softmax-expectation decode + argmax
+// (whenet.py:10-13, 28-33; utils.py:7-11).
+struct HeadsArgs {
+    const void* x;         // [n][49][1280] T  (head conv output), or nullptr with feat_in
+    const float* feat_in;  // [n][1280] (decode-only / tests) or nullptr
+    const float* logits_in;// [n][252] decode-only or nullptr
+    const float* w;        // [1280][252]
+    const float* b;        // [252]
+    float* feat;           // [n][1280] or nullptr
+    float* logits;         // [n][252] or nullptr
+    float* ypr;            // [n][3]
+    int32_t* argmax;       // [n][3] or nullptr
+    int n;
+};
+void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream);
+
+// ---- convert.hip ------------------------------------------------------------------------
+void launch_f32_to_act(const float* src, void* dst, size_t count, int dtype, hipStream_t stream);
+void launch_act_to_f32(const void* src, float* dst, size_t count, int dtype, hipStream_t stream);
+
+const char* kernel_name_stem(int dtype);
+const char* kernel_name_dw(int dtype, int k, int s);
+const char* kernel_name_pw(int dtype, int impl, bool gate, bool res, int act);
+
+}  // namespace whenet

@@ -1,0 +1,165 @@
+"""Drop-in replacement for the reference module ``whenet`` (/root/reference/whenet.py).
+
+    from whenet import WHENet            # demo.py:3, demo_video.py:3
+    model = WHENet('WHENet.h5')          # demo.py:20     (positional snapshot path)
+    model = WHENet(snapshot=path)        # demo_video.py:40
+    print(model.model.summary())         # demo.py:22
+    yaw, pitch, roll = model.get_angle(img_rgb_uint8[N,224,224,3])     # demo.py:14, demo_video.py:27
+
+Same class name, constructor, method names, argument meaning, return types (three float32
+arrays of shape (N,)) and error classes (ValueError for a bad input shape, OSError for a
+missing snapshot) as the reference.  Behind it, instead of Keras/TensorFlow, is
+libwhenet_hip.so: hand-written gfx950 kernels reached through a C ABI (include/whenet_hip.h)
+via ctypes.  There is no NumPy/CPU implementation in this module: without the built library
+and an MI355X the constructor raises.
+
+Extras that the reference does not have (keyword-only, all optional):
+  device=0            GPU ordinal
+  dtype='f32'|'f16'   activation / 1x1-weight type (f32 = parity configuration)
+  .predict            alias of get_angle (BASELINE.json words the API as WHENet.predict(crop))
+  .last_logits, .last_argmax   what Model.predict returned for the last call, and the bin argmax
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+from whenet_hip import _lib, spec  # noqa: E402
+from whenet_hip import weights as _weights  # noqa: E402
+
+_DTYPES = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32,
+           "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16}
+
+
+def _as_uint8_crops(img) -> np.ndarray:
+    """Validate like Keras would at Model.predict (ValueError on wrong rank/shape) and return
+    a contiguous uint8 array.  The reference divides by 255 whatever the dtype
+    (whenet.py:25); integer-valued arrays in [0,255] of any dtype are therefore accepted."""
+    a = np.asarray(img)
+    if a.ndim != 4 or tuple(a.shape[1:]) != (spec.IMG, spec.IMG, 3):
+        raise ValueError(f"Error when checking input: expected input to have shape "
+                         f"(None, 224, 224, 3) but got array with shape {a.shape}")
+    if a.dtype != np.uint8:
+        if a.size and (a.min() < 0 or a.max() > 255 or not np.all(a == np.rint(a))):
+            raise ValueError("get_angle expects 8-bit RGB crops (integer values 0..255), as produced by "
+                             "cv2.resize on an image (demo.py:11)")
+        a = a.astype(np.uint8)
+    return np.ascontiguousarray(a)
+
+
+class _Model:
+    """Stand-in for the inner ``keras.models.Model`` (whenet.py:14): ``summary()`` (demo.py:22)
+    and ``predict()`` (whenet.py:27)."""
+
+    def __init__(self, outer: "WHENet"):
+        self._outer = outer
+
+    def summary(self):
+        h = self._outer._handle
+        info = h.info()
+        print("_" * 78)
+        print(f"{'Layer (kernel)':34s}{'Output shape':22s}{'Param #':>12s}")
+        print("=" * 78)
+        shapes = {t.name: t.shape for t in spec.tensors()}
+
+        def count(prefixes):
+            return sum(int(np.prod(s)) for n, s in shapes.items() if any(n.startswith(p + "/") for p in prefixes))
+
+        print(f"{'stem conv3x3/s2+BN+swish':34s}{'(None, 112, 112, 32)':22s}{count(['stem']):>12,d}")
+        for b in spec.blocks():
+            p = f"b{b.index}"
+            desc = f"{p} MBConv{b.expand} k{b.k} s{b.s}" + (" +skip" if b.has_skip else "")
+            print(f"{desc:34s}{str((None, b.h_out, b.h_out, b.cout)):22s}{count([p]):>12,d}")
+        print(f"{'head conv1x1+BN+swish':34s}{'(None, 7, 7, 1280)':22s}{count(['head']):>12,d}")
+        print(f"{'global_average_pooling2d':34s}{'(None, 1280)':22s}{0:>12,d}")
+        for n, k in (("yaw_new", 120), ("pitch_new", 66), ("roll_new", 66)):
+            print(f"{n + ' (Dense)':34s}{str((None, k)):22s}{count([n.split('_')[0]]):>12,d}")
+        print("=" * 78)
+        total = info.params_backbone + info.params_heads
+        print(f"Total params: {total:,d}")
+        print(f"Backend: libwhenet_hip on {info.device_name.decode()} ({info.arch.decode()}), "
+              f"dtype {'f16' if info.dtype == _lib.F16 else 'f32'}, {info.n_kernels_per_forward} kernels/forward")
+        print("_" * 78)
+
+    def predict(self, x, batch_size=8, **_):
+        """Model.predict(img, batch_size=8) (whenet.py:27).  ``x`` is the *normalised* float
+        image the reference passes; the HIP path consumes bytes (it normalises through a LUT),
+        so ``x`` is mapped back to the uint8 crop it came from -- exactly invertible for
+        anything produced by whenet.py:23-26 -- and rejected otherwise."""
+        x = np.asarray(x)
+        if x.ndim != 4 or tuple(x.shape[1:]) != (spec.IMG, spec.IMG, 3):
+            raise ValueError(f"Error when checking input: expected input to have shape "
+                             f"(None, 224, 224, 3) but got array with shape {x.shape}")
+        mean = np.array(spec.MEAN)
+        std = np.array(spec.STD)
+        u8f = np.rint((x.astype(np.float64) * std + mean) * 255.0)
+        if u8f.min() < 0 or u8f.max() > 255:
+            raise ValueError("predict(): input is not a normalised 8-bit image")
+        u8 = u8f.astype(np.uint8)
+        back = ((u8 / 255 - mean) / std)
+        if not np.allclose(back, x, rtol=0, atol=1e-5):
+            raise ValueError("predict(): input is not a normalised 8-bit image (whenet.py:23-26)")
+        _, _, lg = self._outer._forward(u8)
+        return [lg[:, :120].copy(), lg[:, 120:186].copy(), lg[:, 186:].copy()]
+
+
+class WHENet:
+    def __init__(self, snapshot=None, *, device=0, dtype="f32"):
+        if isinstance(dtype, str):
+            if dtype.lower() not in _DTYPES:
+                raise ValueError(f"dtype must be one of {sorted(set(_DTYPES))}")
+            dtype = _DTYPES[dtype.lower()]
+        if snapshot is None:
+            # whenet.py:15: no snapshot -> the freshly initialised network.  Ours: the seeded
+            # random-init snapshot (whenet_hip/weights.py::synthetic).
+            snapshot = _weights.pack(_weights.synthetic(1234))
+        elif isinstance(snapshot, (str, os.PathLike)):
+            path = os.fspath(snapshot)
+            if not os.path.exists(path):
+                raise OSError(f"Unable to open file (unable to open file: name = '{path}')")
+            if not _weights.is_packed(path):
+                from whenet_hip import keras_h5
+                snapshot = keras_h5.load_as_packed(path)          # Keras HDF5 -> WHNPACK1 bytes
+            else:
+                snapshot = path
+        self._handle = _lib.Handle(snapshot, device=int(device), dtype=dtype)
+        self.model = _Model(self)
+        self.idx_tensor = [idx for idx in range(66)]                       # whenet.py:17-20
+        self.idx_tensor = np.array(self.idx_tensor, dtype=np.float32)
+        self.idx_tensor_yaw = [idx for idx in range(120)]
+        self.idx_tensor_yaw = np.array(self.idx_tensor_yaw, dtype=np.float32)
+        self.last_logits = None
+        self.last_argmax = None
+
+    def _forward(self, u8: np.ndarray):
+        ypr, am, lg = self._handle.forward(u8, want_logits=True)
+        self.last_logits, self.last_argmax = lg, am
+        return ypr, am, lg
+
+    def get_angle(self, img):
+        """whenet.py:22-34.  img: [N,224,224,3] RGB uint8 -> (yaw, pitch, roll), float32 (N,)."""
+        u8 = _as_uint8_crops(img)
+        if u8.shape[0] == 0:
+            e = np.empty((0,), np.float32)
+            return e, e.copy(), e.copy()
+        ypr, _, _ = self._forward(u8)
+        return ypr[:, 0].copy(), ypr[:, 1].copy(), ypr[:, 2].copy()
+
+    predict = get_angle
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            self._handle.close()
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,261 @@
+"""ctypes binding of libwhenet_hip.so (include/whenet_hip.h).  Thin: argument marshalling
+and error-code -> exception mapping only.  There is no Python/NumPy implementation of the
+path behind it -- if the library or a gfx950 device is missing, callers get an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+ABI_VERSION = 1
+F32, F16 = 0, 1
+OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EFORMAT, EHIP = 0, -2, -5, -12, -19, -22, -74, -1000
+MAX_INFLIGHT = 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "lib", "libwhenet_hip.so")
+
+
+class Info(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("dtype", C.c_int32), ("device_id", C.c_int32),
+                ("compute_units", C.c_int32), ("params_backbone", C.c_int64),
+                ("params_heads", C.c_int64), ("n_tensors", C.c_int32),
+                ("n_kernels_per_forward", C.c_int32), ("macs_per_crop", C.c_int64),
+                ("arena_bytes", C.c_int64), ("capacity", C.c_int32), ("graph_enabled", C.c_int32),
+                ("device_name", C.c_char * 64), ("arch", C.c_char * 32)]
+
+
+class LaunchStat(C.Structure):
+    _fields_ = [("layer", C.c_char * 32), ("kind", C.c_char * 16), ("kernel", C.c_char * 64),
+                ("avg_us", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
+
+
+_P = C.c_void_p
+_PROTOS = {
+    "whenet_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "whenet_create_from_memory": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
+    "whenet_destroy": (None, [_P]),
+    "whenet_last_error": (C.c_char_p, [_P]),
+    "whenet_get_info": (C.c_int, [_P, C.POINTER(Info)]),
+    "whenet_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
+    "whenet_forward_u8": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "whenet_forward_u8_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    "whenet_sync": (C.c_int, [_P]),
+    "whenet_submit_u8": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "whenet_collect": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "whenet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.POINTER(C.c_int)]),
+    "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
+    "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    "whenet_op_head": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    "whenet_op_decode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "whenet_block_spec": (C.c_int, [C.c_int, C.POINTER(C.c_int32 * 8)]),
+    "whenet_dw_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32 * 12)]),
+    "whenet_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "whenet_device_free": (C.c_int, [_P, _P]),
+    "whenet_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "whenet_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every symbol the header declares (works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("WHENET_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise OSError(f"{path} not found: build it with `python __graft_entry__.py` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(os.path.abspath(path))
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class WhenetError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libwhenet_hip error {code}: {msg}")
+        self.code = code
+
+
+def raise_for(code: int, msg: str):
+    """Map ABI codes onto what the reference's Keras path raises:
+    missing/unreadable snapshot -> OSError; bad shape/argument/format -> ValueError."""
+    if code == OK:
+        return
+    if code in (ENOENT, EIO):
+        raise OSError(msg)
+    if code in (EINVAL, EFORMAT):
+        raise ValueError(msg)
+    if code == ENOMEM:
+        raise MemoryError(msg)
+    raise WhenetError(code, msg)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+class Handle:
+    """Owns one whenet_t*."""
+
+    def __init__(self, snapshot, device: int = 0, dtype: int = F32):
+        lib = load()
+        h = _P()
+        if isinstance(snapshot, (bytes, bytearray, memoryview)):
+            buf = (C.c_char * len(snapshot)).from_buffer_copy(bytes(snapshot))
+            rc = lib.whenet_create_from_memory(C.cast(buf, _P), len(snapshot), device, dtype, C.byref(h))
+        else:
+            rc = lib.whenet_create(os.fsencode(snapshot), device, dtype, C.byref(h))
+        if rc != OK:
+            raise_for(rc, (lib.whenet_last_error(None) or b"").decode(errors="replace"))
+        self._h = h
+        self._lib = lib
+        self.dtype = dtype
+        self.device = device
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise_for(rc, (self._lib.whenet_last_error(self._h) or b"").decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.whenet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot path ---------------------------------------------------------------------
+    def forward(self, crops: np.ndarray, want_logits: bool = True):
+        n = crops.shape[0]
+        ypr = np.empty((n, 3), np.float32)
+        am = np.empty((n, 3), np.int32)
+        lg = np.empty((n, 252), np.float32) if want_logits else None
+        self._check(self._lib.whenet_forward_u8(self._h, _ptr(crops), n, _ptr(ypr), _ptr(am), _ptr(lg)))
+        return ypr, am, lg
+
+    def forward_device(self, d_crops: int, n: int, d_ypr: int, d_argmax: int = 0, d_logits: int = 0, stream: int = 0):
+        self._check(self._lib.whenet_forward_u8_device(self._h, d_crops, n, d_ypr, d_argmax or None,
+                                                       d_logits or None, stream or None))
+
+    def sync(self):
+        self._check(self._lib.whenet_sync(self._h))
+
+    def submit(self, crops: np.ndarray) -> int:
+        t = C.c_int(-1)
+        self._check(self._lib.whenet_submit_u8(self._h, _ptr(crops), crops.shape[0], C.byref(t)))
+        return t.value
+
+    def collect(self, ticket: int, n: int, want_logits: bool = False):
+        ypr = np.empty((n, 3), np.float32)
+        am = np.empty((n, 3), np.int32)
+        lg = np.empty((n, 252), np.float32) if want_logits else None
+        self._check(self._lib.whenet_collect(self._h, ticket, _ptr(ypr), _ptr(am), _ptr(lg)))
+        return ypr, am, lg
+
+    # ---- misc -------------------------------------------------------------------------
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.whenet_set_option(self._h, key.encode(), int(value)))
+
+    def info(self) -> Info:
+        out = Info()
+        self._check(self._lib.whenet_get_info(self._h, C.byref(out)))
+        return out
+
+    def profile(self, d_crops: int, n: int, iters: int = 10):
+        cap = 128
+        arr = (LaunchStat * cap)()
+        cnt = C.c_int(0)
+        self._check(self._lib.whenet_profile(self._h, d_crops, n, iters, arr, cap, C.byref(cnt)))
+        out = []
+        for i in range(min(cnt.value, cap)):
+            s = arr[i]
+            out.append({"layer": s.layer.decode(), "kind": s.kind.decode(), "kernel": s.kernel.decode(),
+                        "avg_us": s.avg_us, "alg_bytes": s.alg_bytes, "alg_flops": s.alg_flops})
+        return out
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = _P()
+        self._check(self._lib.whenet_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr: int):
+        self._check(self._lib.whenet_device_free(self._h, ptr))
+
+    def h2d(self, d_ptr: int, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        self._check(self._lib.whenet_memcpy_h2d(self._h, d_ptr, _ptr(a), a.nbytes))
+
+    def d2h(self, a: np.ndarray, d_ptr: int):
+        self._check(self._lib.whenet_memcpy_d2h(self._h, _ptr(a), d_ptr, a.nbytes))
+
+    # ---- single-stage entry points (tests) ----------------------------------------------
+    def op_stem(self, crops: np.ndarray) -> np.ndarray:
+        n = crops.shape[0]
+        out = np.empty((n, 112, 112, 32), np.float32)
+        self._check(self._lib.whenet_op_stem(self._h, _ptr(crops), n, _ptr(out)))
+        return out
+
+    def op_block(self, index: int, x: np.ndarray):
+        from . import spec
+        b = spec.blocks()[index - 1]
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.shape[0]
+        assert x.shape[1:] == (b.h_in, b.h_in, b.cin), (x.shape, b)
+        ex = np.empty((n, b.h_in, b.h_in, b.cexp), np.float32) if b.has_expand else None
+        dw = np.empty((n, b.h_out, b.h_out, b.cexp), np.float32)
+        gate = np.empty((n, b.cexp), np.float32)
+        out = np.empty((n, b.h_out, b.h_out, b.cout), np.float32)
+        self._check(self._lib.whenet_op_block(self._h, index, _ptr(x), n, _ptr(ex), _ptr(dw), _ptr(gate), _ptr(out)))
+        return {"expand": ex, "dw": dw, "gate": gate, "out": out}
+
+    def op_head(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.shape[0]
+        assert x.shape[1:] == (7, 7, 320)
+        feat = np.empty((n, 1280), np.float32)
+        lg = np.empty((n, 252), np.float32)
+        ypr = np.empty((n, 3), np.float32)
+        am = np.empty((n, 3), np.int32)
+        self._check(self._lib.whenet_op_head(self._h, _ptr(x), n, _ptr(feat), _ptr(lg), _ptr(ypr), _ptr(am)))
+        return {"feat": feat, "logits": lg, "ypr": ypr, "argmax": am}
+
+    def op_decode(self, logits: np.ndarray):
+        lg = np.ascontiguousarray(logits, np.float32)
+        n = lg.shape[0]
+        ypr = np.empty((n, 3), np.float32)
+        am = np.empty((n, 3), np.int32)
+        self._check(self._lib.whenet_op_decode(self._h, _ptr(lg), n, _ptr(ypr), _ptr(am)))
+        return ypr, am
+
+
+def block_spec(index: int):
+    lib = load()
+    out = (C.c_int32 * 8)()
+    rc = lib.whenet_block_spec(index, C.byref(out))
+    if rc != OK:
+        raise_for(rc, f"whenet_block_spec({index})")
+    return tuple(out)
+
+
+def dw_plan(dtype: int, index: int) -> dict:
+    lib = load()
+    out = (C.c_int32 * 12)()
+    rc = lib.whenet_dw_plan(dtype, index, C.byref(out))
+    if rc != OK:
+        raise_for(rc, f"whenet_dw_plan({dtype},{index})")
+    keys = ("threads", "CV", "TH", "NSX", "tiles_x", "tiles_y", "chunks", "IH", "IW", "lds_bytes", "pad", "C")
+    return dict(zip(keys, out))

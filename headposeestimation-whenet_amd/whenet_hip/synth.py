@@ -35,7 +35,8 @@ def scene_crops(n: int, seed: int = 0) -> np.ndarray:
             cy, cx = rng.uniform(-0.7, 0.7, size=2)
             ry, rx = rng.uniform(0.15, 0.8, size=2)
             d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
-            m = 1.0 / (1.0 + np.exp((d - 1.0) * rng.uniform(4, 40)))
+            with np.errstate(over="ignore"):
+                m = 1.0 / (1.0 + np.exp((d - 1.0) * rng.uniform(4, 40)))
             col = rng.uniform(0, 1, size=3)
             img = img * (1 - m[..., None]) + col * m[..., None]
         img += rng.normal(0, rng.uniform(0.0, 0.06), size=img.shape)   # sensor noise

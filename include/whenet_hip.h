@@ -1,0 +1,164 @@
+/*
+ * libwhenet_hip.so -- C ABI of the MI355X-native WHENet inference path.
+ *
+ * The reference has no FFI / plugin / operator interface for this path: its boundary is
+ * the Python class `WHENet` in module `whenet` (/root/reference/whenet.py:6-34), whose
+ * arithmetic is delegated to Keras/TensorFlow.  Every entry point below therefore cites
+ * the Python statement(s) of the reference it replaces; the ctypes binding a maintainer
+ * adds on the reference side is the drop-in `whenet.py` of this repo.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns 0 (WHENET_OK) or a negative code and never throws;
+ *     whenet_last_error() gives the message for the last failure on that handle
+ *     (or, with a NULL handle, of the last failed whenet_create* on this thread);
+ *   - all outputs are caller-allocated; inputs are never written;
+ *   - a handle owns one device, one stream, its device weights and activation arena, and is
+ *     NOT thread-safe: use one handle per host thread / per GPU;
+ *   - crops are uint8 RGB, NHWC, [n,224,224,3] contiguous -- exactly the array the
+ *     reference's callers build (demo.py:8-12, demo_video.py:21-24);
+ *   - there is no CPU fallback anywhere in this library: without a gfx950 device
+ *     whenet_create* fails with WHENET_ENODEV.
+ */
+#ifndef WHENET_HIP_H
+#define WHENET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WHENET_ABI_VERSION 1
+#define WHENET_API __attribute__((visibility("default")))
+
+/* return codes (negative errno-style) */
+#define WHENET_OK        0
+#define WHENET_ENOENT   (-2)    /* snapshot file missing/unreadable  (Keras: OSError)        */
+#define WHENET_EIO      (-5)
+#define WHENET_ENOMEM   (-12)
+#define WHENET_ENODEV   (-19)   /* no usable gfx950 device                                  */
+#define WHENET_EINVAL   (-22)   /* bad argument / shape            (Keras: ValueError)      */
+#define WHENET_EFORMAT  (-74)   /* not a WHNPACK1 snapshot or tensor shapes do not match    */
+#define WHENET_EHIP     (-1000) /* HIP runtime call or kernel launch failed                  */
+
+/* arithmetic type of activations and 1x1-conv weights (accumulation is always f32) */
+#define WHENET_F32 0            /* parity configuration: <=1e-3 deg vs the float64 oracle   */
+#define WHENET_F16 1            /* throughput configuration (north-star fp16)               */
+
+#define WHENET_IMG      224
+#define WHENET_NLOGITS  252     /* 120 yaw | 66 pitch | 66 roll  (whenet.py:11-13)          */
+#define WHENET_NFEAT    1280
+
+typedef struct whenet_ctx whenet_t;
+
+typedef struct whenet_info {
+    int32_t abi_version;
+    int32_t dtype;              /* WHENET_F32 / WHENET_F16 */
+    int32_t device_id;
+    int32_t compute_units;
+    int64_t params_backbone;    /* 4,049,564 */
+    int64_t params_heads;       /*   322,812 */
+    int32_t n_tensors;          /* 315 */
+    int32_t n_kernels_per_forward;
+    int64_t macs_per_crop;      /* 384,857,312 */
+    int64_t arena_bytes;        /* current activation arena */
+    int32_t capacity;           /* crops the arena currently holds */
+    int32_t graph_enabled;
+    char    device_name[64];
+    char    arch[32];
+} whenet_info_t;
+
+/* One kernel launch of a forward pass, as timed by whenet_profile(). */
+typedef struct whenet_launch_stat {
+    char    layer[32];          /* e.g. "b3/dw", "b3/project", "stem", "heads"              */
+    char    kind[16];           /* stem | pw | dw | se | heads                              */
+    char    kernel[64];         /* kernel symbol family, matches rocprofv3's kernel name    */
+    double  avg_us;             /* mean duration over the profiled iterations (HIP events)  */
+    double  alg_bytes;          /* algorithmic bytes of this launch: in + out (+skip) once  */
+    double  alg_flops;          /* 2 * MACs of this launch                                   */
+} whenet_launch_stat_t;
+
+/* ---- construction: replaces WHENet.__init__ (whenet.py:7-20): graph build +
+ * model.load_weights(snapshot).  `snapshot_path` is a WHNPACK1 file (the 315 Keras arrays;
+ * tools/convert_h5.py turns a Keras HDF5 snapshot into one). */
+WHENET_API int whenet_create(const char* snapshot_path, int device_id, int dtype, whenet_t** out);
+WHENET_API int whenet_create_from_memory(const void* snapshot, size_t nbytes, int device_id, int dtype,
+                              whenet_t** out);
+WHENET_API void whenet_destroy(whenet_t* h);
+WHENET_API const char* whenet_last_error(const whenet_t* h);
+WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
+
+/* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
+ *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
+WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
+
+/* ---- the hot path: replaces WHENet.get_angle (whenet.py:22-34) =
+ * normalise (23-26) -> Model.predict (27) -> softmax-expectation decode (28-33).
+ *   crops   uint8 [n,224,224,3] RGB
+ *   ypr     float [n,3]   yaw, pitch, roll in degrees           (required)
+ *   argmax  int32 [n,3]   argmax bin of each head's logits      (may be NULL)
+ *   logits  float [n,252] what Model.predict returns, concatenated (may be NULL)
+ * Host-pointer form: copies in, runs, copies out, returns when the results are in place. */
+WHENET_API int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n,
+                      float* ypr, int32_t* argmax, float* logits);
+
+/* Device-pointer form: all pointers are device memory on the handle's GPU; the work is
+ * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream) and the call returns
+ * without waiting.  This is the form bench.py times (inputs resident in HBM). */
+WHENET_API int whenet_forward_u8_device(whenet_t* h, const uint8_t* d_crops, int n,
+                             float* d_ypr, int32_t* d_argmax, float* d_logits, void* stream);
+WHENET_API int whenet_sync(whenet_t* h);
+
+/* Pipelined host form for per-frame callers (demo_video.py:56-58 runs one get_angle per
+ * detected head, sequentially): submit copies the crops into pinned memory and enqueues
+ * H2D + forward + D2H on the handle's stream; collect waits for that submission. Up to
+ * WHENET_MAX_INFLIGHT submissions may be outstanding, collected in FIFO order. */
+#define WHENET_MAX_INFLIGHT 4
+WHENET_API int whenet_submit_u8(whenet_t* h, const uint8_t* crops, int n, int* ticket);
+WHENET_API int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits);
+
+/* ---- measurement: run `iters` eager forwards of `n` device-resident crops with a HIP
+ * event pair around every kernel launch (on the stream the kernels run on).  Fills up to
+ * `cap` entries, one per launch of a forward in launch order; *count = launches/forward. */
+WHENET_API int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int iters,
+                   whenet_launch_stat_t* stats, int cap, int* count);
+
+/* ---- single-stage entry points (host pointers, float32 activations in/out, converted to
+ * the handle's dtype on the device).  They run exactly the kernels the forward uses, on
+ * caller-supplied inputs, so each kernel can be compared with the oracle on every layer
+ * shape.  Any output pointer may be NULL. */
+/* stem: normalise + Conv3x3/s2 + BN + Swish.  out [n,112,112,32] */
+WHENET_API int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* out);
+/* MBConv block `index` (1..16) on input [n,H,W,Cin]:
+ *   expand_out [n,H,W,Cexp] (NULL for block 1), dw_out [n,Ho,Wo,Cexp], gate [n,Cexp],
+ *   out [n,Ho,Wo,Cout] (after project + BN + skip) */
+WHENET_API int whenet_op_block(whenet_t* h, int index, const float* in, int n,
+                    float* expand_out, float* dw_out, float* gate, float* out);
+/* head: Conv1x1(1280)+BN+Swish + GAP + Dense heads + decode on input [n,7,7,320]:
+ *   feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3] */
+WHENET_API int whenet_op_head(whenet_t* h, const float* in, int n,
+                   float* feat, float* logits, float* ypr, int32_t* argmax);
+/* decode only (whenet.py:28-33) on caller logits [n,252] -> ypr [n,3], argmax [n,3] */
+WHENET_API int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax);
+
+/* layer geometry as the engine sees it (for cross-checking against whenet_hip/spec.py):
+ * fills out[0..7] = {k, stride, expand, cin, cout, h_in, h_out, se_reduced} for block
+ * `index` (1..16). */
+WHENET_API int whenet_block_spec(int index, int32_t out[8]);
+
+/* the depthwise tile plan of block `index` for `dtype` (pure host logic; no GPU needed):
+ * out = {threads, CV, TH, NSX, tiles_x, tiles_y, chunks, IH, IW, lds_bytes, pad_before, C} */
+WHENET_API int whenet_dw_plan(int dtype, int index, int32_t out[12]);
+
+/* raw device-memory helpers so a host without torch can use the device-pointer form */
+WHENET_API int whenet_device_alloc(whenet_t* h, size_t nbytes, void** d_ptr);
+WHENET_API int whenet_device_free(whenet_t* h, void* d_ptr);
+WHENET_API int whenet_memcpy_h2d(whenet_t* h, void* d_dst, const void* src, size_t nbytes);
+WHENET_API int whenet_memcpy_d2h(whenet_t* h, void* dst, const void* d_src, size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHENET_HIP_H */
