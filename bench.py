@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dump-layers", default="", help="write the per-launch profile (JSON) to this path")
     return ap.parse_args()
 
 
@@ -149,6 +150,9 @@ def main():
 
     # ---- per-kernel roofline (HIP events around every launch, same stream, eager) ----------
     stats = h.profile(d_crops.data_ptr(), B, args.profile_iters)
+    if args.dump_layers and rank == 0:
+        with open(args.dump_layers, "w") as f:
+            json.dump({"batch": B, "dtype": args.dtype, "launches": stats}, f, indent=1)
     by_kernel = {}
     for s in stats:
         k = by_kernel.setdefault(s["kernel"], {"us": 0.0, "bytes": 0.0, "flops": 0.0, "launches": 0, "kind": s["kind"]})

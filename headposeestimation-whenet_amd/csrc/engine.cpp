@@ -103,7 +103,7 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
         b.dw.plan = plan_dw(dtype_, hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C);
         b.se.C = hb.se.C;
         b.se.R = hb.se.R;
-        b.se.w1t = upload(hb.se.w1t);
+        b.se.w1p = upload(hb.se.w1p);
         b.se.b1 = upload(hb.se.b1);
         b.se.w2 = upload(hb.se.w2);
         b.se.b2 = upload(hb.se.b2);
@@ -311,7 +311,7 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
         a.partial = partial_;
         a.ntiles = b.dw.plan.ntiles();
         a.inv_hw = 1.0f / float(hw_out);
-        a.w1t = b.se.w1t;
+        a.w1p = b.se.w1p;
         a.b1 = b.se.b1;
         a.w2 = b.se.w2;
         a.b2 = b.se.b2;
@@ -319,7 +319,7 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
         a.C = b.se.C;
         a.R = b.se.R;
         a.n = n;
-        R(p + "/se", "se", "whenet_se_kernel", double(n) * (a.ntiles + 1) * a.C * 4.0 + 2.0 * a.C * a.R * 4.0,
+        R(p + "/se", "se", "whenet_se_kernel<RP>", double(n) * (a.ntiles + 1) * a.C * 4.0 + 2.0 * a.C * a.R * 4.0,
           4.0 * n * a.C * a.R, [&] { launch_se(a, s); });
     }
     {

@@ -29,7 +29,7 @@ struct DevDw {
 };
 struct DevSe {
     int C = 0, R = 0;
-    float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float *w1p = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
 };
 struct DevBlock {
     BlockSpec spec;

@@ -29,13 +29,20 @@ __global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__
     const int b = blockIdx.x;
 
     if (logits_in == nullptr) {
-        // ---- GAP: mean over the 49 positions (whenet.py:10) -------------------------------
+        // ---- GAP: mean over the 49 positions (whenet.py:10); lane <-> 4 channels ------------
         if (x != nullptr) {
+            using V4 = T __attribute__((ext_vector_type(4)));
             const T* xb = x + size_t(b) * HW * FEAT;
-            for (int c = tid; c < FEAT; c += 256) {
-                float t = 0.0f;
-                for (int p = 0; p < HW; ++p) t += float(xb[size_t(p) * FEAT + c]);
-                s_feat[c] = t * (1.0f / 49.0f);
+            for (int c4 = tid; c4 < FEAT / 4; c4 += 256) {
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 7
+                for (int p = 0; p < HW; ++p) {
+                    const V4 v = *reinterpret_cast<const V4*>(xb + size_t(p) * FEAT + c4 * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[i] += float(v[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_feat[c4 * 4 + i] = t[i] * (1.0f / 49.0f);
             }
         } else {
             for (int c = tid; c < FEAT; c += 256) s_feat[c] = feat_in[size_t(b) * FEAT + c];
@@ -45,23 +52,22 @@ __global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__
             for (int c = tid; c < FEAT; c += 256) feat_out[size_t(b) * FEAT + c] = s_feat[c];
 
         // ---- Dense: logits[j] = sum_c feat[c]*W[c][j] + b[j]  (whenet.py:11-13) ------------
-        // 4 waves split the 1280-long contraction; lane j of each wave owns logits j, j+64, ...
+        // 4 waves split the 1280-long contraction; lane l owns logits 4l..4l+3 (16-byte loads of
+        // the [1280][252] kernel rows, 8 rows in flight).
         const int wave = tid >> 6, lane = tid & 63;
-        const int c_lo = wave * (FEAT / 4), c_hi = c_lo + FEAT / 4;
+        const int c_lo = wave * (FEAT / 4);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = c_lo; c < c_hi; ++c) {
-            const float f = s_feat[c];
-            const float* wr = w + size_t(c) * N_LOGITS;
+        if (lane < N_LOGITS / 4) {
+            const float* wr = w + size_t(c_lo) * N_LOGITS + lane * 4;
+#pragma unroll 8
+            for (int c = 0; c < FEAT / 4; ++c) {
+                const float f = s_feat[c_lo + c];
+                const float4v wv = *reinterpret_cast<const float4v*>(wr + size_t(c) * N_LOGITS);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int j = lane + 64 * i;
-                if (j < N_LOGITS) acc[i] = fmaf(f, wr[j], acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(f, wv[i], acc[i]);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = lane + 64 * i;
-            if (j < N_LOGITS) s_part[wave][j] = acc[i];
+            for (int i = 0; i < 4; ++i) s_part[wave][lane * 4 + i] = acc[i];
         }
         __syncthreads();
         if (tid < N_LOGITS) s_logit[tid] = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + bvec[tid];

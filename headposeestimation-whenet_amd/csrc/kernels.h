@@ -50,7 +50,7 @@ struct SeArgs {
     const float* partial;  // [n][ntiles][C]
     int ntiles;
     float inv_hw;
-    const float* w1t;      // [R][C]
+    const float* w1p;      // [C][RP]  se_reduce kernel, R zero-padded to a multiple of 4
     const float* b1;       // [R]
     const float* w2;       // [R][C]
     const float* b2;       // [C]
@@ -58,6 +58,7 @@ struct SeArgs {
     int C, R, n;
 };
 void launch_se(const SeArgs& a, hipStream_t stream);
+int se_padded_r(int R);
 
 // ---- pw.hip -----------------------------------------------------------------------------
 // 1x1 convolution as an MFMA GEMM over M = n*H*W rows:

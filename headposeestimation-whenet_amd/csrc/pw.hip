@@ -47,7 +47,12 @@ template <> struct Mfma<float> {
     }
 };
 
-template <typename T, int NT, bool GATE, bool RES, int ACT>
+// NT  32-wide out-channel tiles per wave;  U  k-steps whose loads are issued together (software
+// pipelining: (1+NT)*U 16-byte loads in flight per lane before the first MFMA of the group);
+// SK  split-K factor: 1 = the 4 waves of a workgroup own 4 different 32-row strips,
+//     4 = the 4 waves split the k-steps of ONE strip (interleaved) and combine through LDS --
+//     used when there are too few rows to fill the chip (batch 1: M = 49..3136).
+template <typename T, int NT, int U, int SK, bool GATE, bool RES, int ACT>
 __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ gate, const T* __restrict__ res,
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
                                                         int HW, int MT, int NCH) {
     constexpr int V = Vec<T>::V;
     using VT = typename Vec<T>::type;
+    constexpr int STRIPS = (SK == 1) ? 4 : 1;
 
     // XCD-aware decode of the 1-D grid (see header)
     const int id = blockIdx.x;
@@ -65,8 +71,9 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int m0 = (mt * 4 + wave) * 32;
-    if (m0 >= M) return;
+    const int m0 = (mt * STRIPS + (SK == 1 ? wave : 0)) * 32;
+    if (SK == 1 && m0 >= M) return;
+    const int kpart = (SK == 1) ? 0 : wave;
     const int nt0 = nch * NT;
     const int g = lane >> 5;
     const int row = m0 + (lane & 31);
@@ -84,10 +91,9 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    for (int ks = 0; ks < KS; ++ks) {
-        const int k = ks * 2 * V + g * V;
+    auto load_a = [&](int ks) -> VT {
         VT a = vec_zero<T>();
-        if (rvalid && k < K) {
+        if (rvalid && ks * 2 * V + g * V < K) {
             a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
             if constexpr (GATE) {
                 float f[V];
@@ -101,14 +107,51 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
                 a = float_to_vec<T>(f);
             }
         }
+        return a;
+    };
+
+    int ks = kpart;
+    for (; ks + (U - 1) * SK < KS; ks += U * SK) {
+        VT a[U];
+        VT w[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const VT* wk = wp + size_t(ks + u * SK) * NTILES * 64;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[u][t] = (nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = load_a(ks + u * SK);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (nt0 + t < NTILES) Mfma<T>::step(w[u][t], a[u], acc[t]);
+    }
+    for (; ks < KS; ks += SK) {
+        const VT a = load_a(ks);
         const VT* wk = wp + size_t(ks) * NTILES * 64;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (nt0 + t < NTILES) {
-                const VT w = wk[t * 64];
-                Mfma<T>::step(w, a, acc[t]);
-            }
+        for (int t = 0; t < NT; ++t)
+            if (nt0 + t < NTILES) Mfma<T>::step(wk[t * 64], a, acc[t]);
+    }
+
+    if constexpr (SK > 1) {
+        __shared__ float s_red[(SK - 1) * NT * 16 * 64];
+        if (wave > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[((wave - 1) * NT * 16 + t * 16 + r) * 64 + lane] = acc[t][r];
         }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < SK - 1; ++w)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += s_red[(w * NT * 16 + t * 16 + r) * 64 + lane];
     }
 
     if (!rvalid) return;
@@ -174,10 +217,10 @@ __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restric
     }
 }
 
-template <typename T, int NT, bool GATE, bool RES, int ACT>
+template <typename T, int NT, int U, int SK, bool GATE, bool RES, int ACT>
 void launch_mfma(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
     const int blocks = 8 * ceil_div(MT, 8) * NCH;
-    hipLaunchKernelGGL((whenet_pw_kernel<T, NT, GATE, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((whenet_pw_kernel<T, NT, U, SK, GATE, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
                        static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, a.gate,
                        static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES, a.HW, MT,
                        NCH);
@@ -192,22 +235,22 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
                            static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.HW);
         return;
     }
+    const int cus = num_cus > 0 ? num_cus : 256;
+    // Deep contractions (K >= 320: the project convs of blocks 7-16 and the head conv, all on
+    // 14x14 / 7x7 maps) split K across the 4 waves of a workgroup.  The rule depends on the
+    // layer only, never on the batch, so a crop's result is bitwise independent of the batch
+    // it travels in (and of how a batch is sharded across GPUs).
+    if (a.K >= 320) {
+        launch_mfma<T, 1, 4, 4, GATE, RES, ACT>(a, ceil_div(a.M, 32), a.NTILES, stream);
+        return;
+    }
     // NT (32-wide out-channel tiles per wave): as many as keep >= 4 workgroups per CU in
     // flight; with fewer rows than that, favour parallelism (NT = 1).
     const int MT = ceil_div(a.M, 128);
-    const int want = 4 * (num_cus > 0 ? num_cus : 256);
-    int NT = 1;
-    const int cands[3] = {4, 2, 1};
-    for (int c : cands) {
-        if (MT * ceil_div(a.NTILES, c) >= want || c == 1) {
-            NT = c;
-            break;
-        }
-    }
-    const int NCH = ceil_div(a.NTILES, NT);
-    if (NT == 4) launch_mfma<T, 4, GATE, RES, ACT>(a, MT, NCH, stream);
-    else if (NT == 2) launch_mfma<T, 2, GATE, RES, ACT>(a, MT, NCH, stream);
-    else launch_mfma<T, 1, GATE, RES, ACT>(a, MT, NCH, stream);
+    const int want = 4 * cus;
+    if (MT * ceil_div(a.NTILES, 4) >= want) launch_mfma<T, 4, 2, 1, GATE, RES, ACT>(a, MT, ceil_div(a.NTILES, 4), stream);
+    else if (MT * ceil_div(a.NTILES, 2) >= want) launch_mfma<T, 2, 4, 1, GATE, RES, ACT>(a, MT, ceil_div(a.NTILES, 2), stream);
+    else launch_mfma<T, 1, 4, 1, GATE, RES, ACT>(a, MT, a.NTILES, stream);
 }
 
 template <typename T>

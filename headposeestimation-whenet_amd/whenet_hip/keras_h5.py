@@ -1,0 +1,223 @@
+"""Keras-2.1.6 HDF5 snapshot  ->  WHNPACK1.
+
+The reference constructs ``WHENet('WHENet.h5')`` and calls ``model.load_weights(snapshot)``
+(/root/reference/whenet.py:15-16, demo.py:20): Keras' *topological* loader, which pairs the
+file's weighted layers with the model's weighted layers **positionally** (file attr
+``layer_names`` order == ``model.layers`` order of the saving model) and checks counts and
+shapes.  This module does the same pairing against whenet_hip/spec.py::tensors() (creation
+order of the 133 weighted layers / 315 arrays), so that the drop-in accepts the reference's own
+snapshot file.  The three Dense heads are additionally matched by their explicit names
+(``yaw_new`` / ``pitch_new`` / ``roll_new``, whenet.py:11-13).
+
+h5py is not importable in the main interpreter of this image; when ``import h5py`` fails the
+HDF5 file is read by a helper interpreter (``$WHENET_H5PY_PYTHON``, default
+/opt/conda/bin/python3.9) running this very file in ``dump`` mode.  [RECOLLECTION of the Keras
+file layout -- re-verify on the first real WHENet.h5: the trained file is absent from the
+reference, .MISSING_LARGE_BLOBS:1.]
+
+CLI:  python keras_h5.py dump  <in.h5>  <out.npz>     (needs h5py)
+      python keras_h5.py write <in.npz> <out.h5>      (needs h5py; test helper)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import tempfile
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+HELPER = os.environ.get("WHENET_H5PY_PYTHON", "/opt/conda/bin/python3.9")
+Layer = Tuple[str, List[Tuple[str, np.ndarray]]]       # (layer name, [(weight name, array)])
+
+
+# --------------------------------------------------------------------------------------------
+# raw HDF5 access (h5py side; runs in whichever interpreter has h5py)
+# --------------------------------------------------------------------------------------------
+def _dump_h5(path: str) -> List[Layer]:
+    import h5py
+    out: List[Layer] = []
+    with h5py.File(path, "r") as f:
+        g = f["model_weights"] if "model_weights" in f and "layer_names" not in f.attrs else f
+        names = [n.decode() if isinstance(n, bytes) else str(n) for n in g.attrs["layer_names"]]
+        for ln in names:
+            lg = g[ln]
+            wn = [n.decode() if isinstance(n, bytes) else str(n) for n in lg.attrs.get("weight_names", [])]
+            if len(wn):
+                out.append((ln, [(n, np.asarray(lg[n])) for n in wn]))
+    return out
+
+
+def _write_h5(path: str, layers: List[Layer]) -> None:
+    import h5py
+    with h5py.File(path, "w") as f:
+        f.attrs["layer_names"] = np.array([ln.encode() for ln, _ in layers])
+        f.attrs["backend"] = b"tensorflow"
+        f.attrs["keras_version"] = b"2.1.6"
+        for ln, ws in layers:
+            g = f.create_group(ln)
+            g.attrs["weight_names"] = np.array([n.encode() for n, _ in ws])
+            for n, a in ws:
+                g.create_dataset(n, data=np.asarray(a, np.float32))
+
+
+def _layers_to_npz(layers: List[Layer], path: str) -> None:
+    d = {}
+    for i, (ln, ws) in enumerate(layers):
+        for j, (n, a) in enumerate(ws):
+            d[f"{i:04d}|{j:02d}|{ln}|{n}"] = a
+    np.savez(path, **d)
+
+
+def _npz_to_layers(path: str) -> List[Layer]:
+    layers: List[Layer] = []
+    with np.load(path) as z:
+        for key in sorted(z.files):
+            i, _, ln, n = key.split("|", 3)
+            if not layers or int(i) != len(layers) - 1:
+                layers.append((ln, []))
+            layers[-1][1].append((n, z[key]))
+    return layers
+
+
+def _helper(mode: str, src: str, dst: str) -> None:
+    if not os.path.exists(HELPER):
+        raise ImportError(f"h5py is not importable here and the helper interpreter {HELPER} does not exist; "
+                          "set WHENET_H5PY_PYTHON or convert the snapshot elsewhere with tools/convert_h5.py")
+    r = subprocess.run([HELPER, os.path.abspath(__file__), mode, src, dst], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise OSError(f"{HELPER} keras_h5.py {mode} failed:\n{r.stderr}")
+
+
+def read_layers(path: str) -> List[Layer]:
+    try:
+        import h5py  # noqa: F401
+        return _dump_h5(path)
+    except ImportError:
+        with tempfile.TemporaryDirectory() as td:
+            npz = os.path.join(td, "dump.npz")
+            _helper("dump", path, npz)
+            return _npz_to_layers(npz)
+
+
+def write_keras_h5(path: str, layers: List[Layer]) -> None:
+    try:
+        import h5py  # noqa: F401
+        _write_h5(path, layers)
+    except ImportError:
+        with tempfile.TemporaryDirectory() as td:
+            npz = os.path.join(td, "layers.npz")
+            _layers_to_npz(layers, npz)
+            _helper("write", npz, path)
+
+
+# --------------------------------------------------------------------------------------------
+# pairing with the WHENet tensor census (main interpreter)
+# --------------------------------------------------------------------------------------------
+def _expected_layers():
+    """[(canonical layer prefix, kind, [tensor names])] in creation order."""
+    from . import spec
+    out, cur = [], None
+    for t in spec.tensors():
+        prefix = t.name.rsplit("/", 1)[0]
+        if cur is None or cur[0] != prefix:
+            cur = (prefix, [])
+            out.append(cur)
+        cur[1].append(t)
+    return out
+
+
+def convert_layers(layers: List[Layer]) -> Dict[str, np.ndarray]:
+    """Positional (topological) pairing, shape-checked; heads matched by name."""
+    expected = _expected_layers()
+    heads = {"yaw": "yaw_new", "pitch": "pitch_new", "roll": "roll_new"}
+    by_name = {ln: ws for ln, ws in layers}
+    body = [(ln, ws) for ln, ws in layers if ln not in heads.values()]
+    exp_body = [e for e in expected if e[0] not in heads]
+    if len(body) != len(exp_body):
+        raise ValueError(f"You are trying to load a weight file containing {len(layers)} weighted layers into a "
+                         f"model with {len(expected)} weighted layers (WHENet: 130 backbone + 3 Dense).")
+    out: Dict[str, np.ndarray] = {}
+    for (prefix, tensors), (ln, ws) in zip(exp_body, body):
+        if len(ws) != len(tensors):
+            raise ValueError(f"layer {ln} (-> {prefix}): {len(ws)} arrays in file, expected {len(tensors)}")
+        for t, (wn, a) in zip(tensors, ws):
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError(f"layer {ln}/{wn} (-> {t.name}): shape {tuple(a.shape)} != expected {t.shape}")
+            out[t.name] = np.asarray(a, np.float32)
+    for prefix, tensors in [e for e in expected if e[0] in heads]:
+        ln = heads[prefix]
+        if ln not in by_name:
+            raise ValueError(f"snapshot has no layer named {ln} (whenet.py:11-13)")
+        ws = by_name[ln]
+        for t, (wn, a) in zip(tensors, ws):
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError(f"layer {ln}/{wn}: shape {tuple(a.shape)} != expected {t.shape}")
+            out[t.name] = np.asarray(a, np.float32)
+    return out
+
+
+def convert(path: str) -> Dict[str, np.ndarray]:
+    return convert_layers(read_layers(path))
+
+
+def load_as_packed(path: str) -> bytes:
+    """Keras .h5 -> WHNPACK1 bytes, cached next to the snapshot as <path>.whnp when writable."""
+    from . import weights as W
+    cache = path + ".whnp"
+    if os.path.exists(cache) and os.path.getmtime(cache) >= os.path.getmtime(path) and W.is_packed(cache):
+        with open(cache, "rb") as f:
+            return f.read()
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic != b"\x89HDF\r\n\x1a\n":
+        raise ValueError(f"{path}: neither a WHNPACK1 snapshot nor an HDF5 file")
+    blob = W.pack(convert(path))
+    try:
+        with open(cache, "wb") as f:
+            f.write(blob)
+    except OSError:
+        pass
+    return blob
+
+
+def to_keras_layers(weights: Dict[str, np.ndarray], offset: int = 0) -> List[Layer]:
+    """Our tensors -> the layer list a Keras 2.1.6 save of the reference model would hold
+    (auto-generated names conv2d_N / batch_normalization_N / depthwise_conv2d_N numbered in
+    creation order from 1+offset; heads by their explicit names).  Test helper."""
+    counters = {"conv2d": offset, "batch_normalization": offset, "depthwise_conv2d": offset}
+    wname = {"kernel": "kernel:0", "bias": "bias:0", "gamma": "gamma:0", "beta": "beta:0",
+             "mean": "moving_mean:0", "var": "moving_variance:0"}
+    layers: List[Layer] = []
+    for prefix, tensors in _expected_layers():
+        leafs = [t.name.rsplit("/", 1)[1] for t in tensors]
+        if prefix in ("yaw", "pitch", "roll"):
+            ln = prefix + "_new"
+        elif "gamma" in leafs:
+            counters["batch_normalization"] += 1
+            ln = f"batch_normalization_{counters['batch_normalization']}"
+        elif prefix.endswith("/dw"):
+            counters["depthwise_conv2d"] += 1
+            ln = f"depthwise_conv2d_{counters['depthwise_conv2d']}"
+        else:
+            counters["conv2d"] += 1
+            ln = f"conv2d_{counters['conv2d']}"
+        ws = []
+        for t, leaf in zip(tensors, leafs):
+            n = wname[leaf]
+            if prefix.endswith("/dw") and leaf == "kernel":
+                n = "depthwise_kernel:0"
+            ws.append((f"{ln}/{n}", weights[t.name]))
+        layers.append((ln, ws))
+    return layers
+
+
+if __name__ == "__main__":
+    mode, src, dst = sys.argv[1:4]
+    if mode == "dump":
+        _layers_to_npz(_dump_h5(src), dst)
+    elif mode == "write":
+        _write_h5(dst, _npz_to_layers(src))
+    else:
+        raise SystemExit(f"unknown mode {mode}")

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Convert a Keras-2.1.6 HDF5 WHENet snapshot (what the reference loads at whenet.py:15-16)
+into the WHNPACK1 container libwhenet_hip.so reads.
+
+    python tools/convert_h5.py WHENet.h5 [WHENet.whnp]
+
+Needs h5py, either in this interpreter or in $WHENET_H5PY_PYTHON (default
+/opt/conda/bin/python3.9).  `WHENet('WHENet.h5')` in the drop-in module does the same
+conversion on the fly and caches it as WHENet.h5.whnp.
+"""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "headposeestimation-whenet_amd"))
+
+from whenet_hip import keras_h5, weights  # noqa: E402
+
+
+def main():
+    if len(sys.argv) < 2:
+        raise SystemExit(__doc__)
+    src = sys.argv[1]
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.splitext(src)[0] + ".whnp"
+    w = keras_h5.convert(src)
+    weights.save(dst, w)
+    print(f"{src} -> {dst}: {len(w)} arrays, sha256 {weights.checksum(w)}")
+
+
+if __name__ == "__main__":
+    main()
