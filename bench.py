@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--profile-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 fp32 latency leg")
+    ap.add_argument("--repeat", type=int, default=1, help="debug: issue every kernel launch this many times")
+    ap.add_argument("--lanes", type=int, default=0, help="concurrent sub-batch chains per forward (0 = engine default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dump-layers", default="", help="write the per-launch profile (JSON) to this path")
     return ap.parse_args()
@@ -117,6 +120,10 @@ def main():
     h = _lib.Handle(blob, device=local_rank, dtype=dt)
     if args.no_graph:
         h.set_option("graph", 0)
+    if args.repeat > 1:
+        h.set_option("repeat", args.repeat)
+    if args.lanes > 0:
+        h.set_option("lanes", args.lanes)
 
     B = args.batch
     crops = synth.noise_crops(B, seed=rank)        # default_rng(seed) uint8
@@ -199,6 +206,7 @@ def main():
         ref_ang = np.stack([ref["yaw"], ref["pitch"], ref["roll"]], axis=1)
         got = d_ypr.cpu().numpy()[:2]
         out["check"] = {"max_abs_deg_vs_f64_oracle": float(np.abs(got - ref_ang).max()), "crops": 2}
+    if rank == 0 and world == 1 and not args.no_latency:
         # configs[1]: batch=1 fp32 latency
         h1 = _lib.Handle(blob, device=local_rank, dtype=_lib.F32)
         lat = []
@@ -212,8 +220,8 @@ def main():
         out["latency_b1"] = {"dtype": "f32", "median_us": float(np.median(lat)), "p99_us": float(np.percentile(lat, 99)),
                              "iters": 1000, "crops_per_s": float(1e6 / np.median(lat))}
         h1.close()
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     h.close()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -88,6 +88,15 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
 
     WHENET_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     WHENET_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    WHENET_HIP_CHECK(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+    for (int i = 0; i < MAX_LANES - 1; ++i) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        WHENET_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        WHENET_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        lane_streams_.push_back(st);
+        join_ev_.push_back(ev);
+    }
 
     d_lut_ = static_cast<float*>(upload_bytes(&m.lut[0][0], sizeof(m.lut)));
     d_stem_w_ = upload(m.stem_w);
@@ -103,7 +112,7 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
         b.dw.plan = plan_dw(dtype_, hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C);
         b.se.C = hb.se.C;
         b.se.R = hb.se.R;
-        b.se.w1p = upload(hb.se.w1p);
+        b.se.w1t = upload(hb.se.w1t);
         b.se.b1 = upload(hb.se.b1);
         b.se.w2 = upload(hb.se.w2);
         b.se.b2 = upload(hb.se.b2);
@@ -139,6 +148,9 @@ Engine::~Engine() {
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
+    for (hipStream_t st : lane_streams_) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t ev : join_ev_) (void)hipEventDestroy(ev);
+    if (fork_ev_) (void)hipEventDestroy(fork_ev_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
 }
@@ -150,6 +162,21 @@ void Engine::set_option(const std::string& key, long value) {
     } else if (key == "pw_impl") {
         WHENET_REQUIRE(value == 0 || value == 1, WHENET_EINVAL, "pw_impl must be 0 (MFMA) or 1 (check kernel)");
         pw_impl_ = int(value);
+        sync();
+        drop_graphs();
+    } else if (key == "lanes") {
+        WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "lanes must be 1..8");
+        lanes_ = int(value);
+        sync();
+        drop_graphs();
+    } else if (key == "min_lane_crops") {
+        WHENET_REQUIRE(value >= 1, WHENET_EINVAL, "min_lane_crops must be >= 1");
+        min_lane_crops_ = int(value);
+        sync();
+        drop_graphs();
+    } else if (key == "repeat") {
+        WHENET_REQUIRE(value >= 1 && value <= 16, WHENET_EINVAL, "repeat must be 1..16");
+        repeat_ = int(value);
         sync();
         drop_graphs();
     } else {
@@ -236,10 +263,11 @@ namespace {
 struct Rec {
     LaunchRecorder* rec;
     hipStream_t s;
+    int repeat = 1;      // debug option "repeat": issue every (idempotent) launch this many times
     template <typename F>
     void operator()(const std::string& layer, const char* kind, const char* kernel, double bytes, double flops, F&& fn) {
         if (!rec) {
-            fn();
+            for (int i = 0; i < repeat; ++i) fn();
             return;
         }
         if (rec->first_pass) {
@@ -262,8 +290,9 @@ struct Rec {
 
 }  // namespace
 
-void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, hipStream_t s, LaunchRecorder* rec) {
-    Rec R{rec, s};
+void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
+                           LaunchRecorder* rec) {
+    Rec R{rec, s, repeat_};
     const BlockSpec& sp = b.spec;
     const std::string p = "b" + std::to_string(sp.index);
     const double es = double(esz());
@@ -276,7 +305,7 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
         a.wp = b.expand.wp;
         a.wdense = b.expand.wdense;
         a.bias = b.expand.bias;
-        a.out = e_;
+        a.out = v.e;
         a.M = n * hw_in;
         a.K = b.expand.K;
         a.N = b.expand.N;
@@ -286,15 +315,15 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
         a.act = ACT_SWISH;
         R(p + "/expand", "pw", kernel_name_pw(dtype_, pw_impl_, false, false, ACT_SWISH), double(a.M) * (a.K + a.N) * es,
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
-        dw_in = e_;
+        dw_in = v.e;
     }
     {
         DwArgs a{};
         a.in = dw_in;
-        a.out = d_;
+        a.out = v.d;
         a.w = b.dw.w;
         a.bias = b.dw.bias;
-        a.partial = partial_;
+        a.partial = v.partial;
         a.k = sp.k;
         a.s = sp.s;
         a.H = sp.h_in;
@@ -308,14 +337,14 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
     }
     {
         SeArgs a{};
-        a.partial = partial_;
+        a.partial = v.partial;
         a.ntiles = b.dw.plan.ntiles();
         a.inv_hw = 1.0f / float(hw_out);
-        a.w1p = b.se.w1p;
+        a.w1t = b.se.w1t;
         a.b1 = b.se.b1;
         a.w2 = b.se.w2;
         a.b2 = b.se.b2;
-        a.gate = gate_;
+        a.gate = v.gate;
         a.C = b.se.C;
         a.R = b.se.R;
         a.n = n;
@@ -324,11 +353,11 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
     }
     {
         PwArgs a{};
-        a.a = d_;
+        a.a = v.d;
         a.wp = b.project.wp;
         a.wdense = b.project.wdense;
         a.bias = b.project.bias;
-        a.gate = gate_;
+        a.gate = v.gate;
         a.res = sp.has_skip() ? in : nullptr;
         a.out = out;
         a.M = n * hw_out;
@@ -344,19 +373,19 @@ void Engine::enqueue_block(const DevBlock& b, const void* in, void* out, int n, 
     }
 }
 
-void Engine::enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
-                             LaunchRecorder* rec) {
-    Rec R{rec, s};
+void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
+                             hipStream_t s, LaunchRecorder* rec) {
+    Rec R{rec, s, repeat_};
     const double es = double(esz());
     {
-        StemArgs a{d_in, x0_, d_stem_w_, d_stem_b_, d_lut_, n};
+        StemArgs a{d_in, v.x0, d_stem_w_, d_stem_b_, d_lut_, n};
         R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
           [&] { launch_stem(a, dtype_, s); });
     }
-    void* cur = x0_;
+    void* cur = v.x0;
     for (const DevBlock& b : blocks_) {
-        void* nxt = (cur == x0_) ? x1_ : x0_;
-        enqueue_block(b, cur, nxt, n, s, rec);
+        void* nxt = (cur == v.x0) ? v.x1 : v.x0;
+        enqueue_block(b, v, cur, nxt, n, s, rec);
         cur = nxt;
     }
     {
@@ -365,7 +394,7 @@ void Engine::enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* 
         a.wp = head_.wp;
         a.wdense = head_.wdense;
         a.bias = head_.bias;
-        a.out = hc_;
+        a.out = v.hc;
         a.M = n * 49;
         a.K = head_.K;
         a.N = head_.N;
@@ -378,7 +407,7 @@ void Engine::enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* 
     }
     {
         HeadsArgs a{};
-        a.x = hc_;
+        a.x = v.hc;
         a.w = d_dense_w_;
         a.b = d_dense_b_;
         a.logits = d_logits;
@@ -391,9 +420,51 @@ void Engine::enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* 
     }
 }
 
+Engine::View Engine::view(int crop_off) const {
+    const size_t o = size_t(crop_off), es = esz();
+    View v;
+    v.x0 = static_cast<char*>(x0_) + o * X_ELEMS * es;
+    v.x1 = static_cast<char*>(x1_) + o * X_ELEMS * es;
+    v.e = static_cast<char*>(e_) + o * E_ELEMS * es;
+    v.d = static_cast<char*>(d_) + o * D_ELEMS * es;
+    v.hc = static_cast<char*>(hc_) + o * HC_ELEMS * es;
+    v.partial = partial_ + o * partial_per_crop_;
+    v.gate = gate_ + o * 1152;
+    return v;
+}
+
+// One forward = up to `lanes_` independent sub-batches, each a 66-kernel chain on its own
+// stream (forked from / joined back into `s` with events, so that under capture they become
+// parallel branches of ONE graph).  Crops are independent, so the split changes nothing in the
+// results; what it buys is overlap: most kernels of this network are short (10-30 us) and
+// latency-bound, and two chains in flight fill each other's launch / drain bubbles.
+void Engine::enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
+    int lanes = lanes_;
+    while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
+    if (lanes <= 1) {
+        enqueue_forward(view(0), d_in, n, d_ypr, d_amax, d_logits, s, nullptr);
+        return;
+    }
+    WHENET_HIP_CHECK(hipEventRecord(fork_ev_, s));
+    int off = 0;
+    for (int i = 0; i < lanes; ++i) {
+        const int cnt = n / lanes + (i < n % lanes ? 1 : 0);
+        hipStream_t st = (i == 0) ? s : lane_streams_[size_t(i - 1)];
+        if (i > 0) WHENET_HIP_CHECK(hipStreamWaitEvent(st, fork_ev_, 0));
+        enqueue_forward(view(off), d_in + size_t(off) * IN_BYTES, cnt, d_ypr + size_t(off) * 3,
+                        d_amax ? d_amax + size_t(off) * 3 : nullptr, d_logits ? d_logits + size_t(off) * N_LOGITS : nullptr,
+                        st, nullptr);
+        if (i > 0) {
+            WHENET_HIP_CHECK(hipEventRecord(join_ev_[size_t(i - 1)], st));
+            WHENET_HIP_CHECK(hipStreamWaitEvent(s, join_ev_[size_t(i - 1)], 0));
+        }
+        off += cnt;
+    }
+}
+
 void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
     if (!use_graph_) {
-        enqueue_forward(d_in, n, d_ypr, d_amax, d_logits, s, nullptr);
+        enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
         return;
     }
     GraphKey key{n, d_in, d_ypr, d_amax, d_logits};
@@ -406,7 +477,7 @@ void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_am
         hipGraph_t graph = nullptr;
         WHENET_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
         try {
-            enqueue_forward(d_in, n, d_ypr, d_amax, d_logits, s, nullptr);
+            enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
         } catch (...) {
             (void)hipStreamEndCapture(s, &graph);
             if (graph) (void)hipGraphDestroy(graph);
@@ -452,6 +523,7 @@ void Engine::sync() {
     DeviceGuard guard(device_);
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(copy_stream_));
+    for (hipStream_t st : lane_streams_) WHENET_HIP_CHECK(hipStreamSynchronize(st));
 }
 
 void Engine::ensure_slot(Slot& s, int n) {
@@ -540,11 +612,11 @@ int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat
         }
     } cleanup{rec};
     // one untimed eager pass so that lazy code-object loading does not land in the numbers
-    enqueue_forward(d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, nullptr);
+    enqueue_forward(view(0), d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, nullptr);
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
     for (int it = 0; it < iters; ++it) {
         rec.cursor = 0;
-        enqueue_forward(d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, &rec);
+        enqueue_forward(view(0), d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, &rec);
         rec.first_pass = false;
         WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
         for (auto& e : rec.entries) {
@@ -601,7 +673,7 @@ void Engine::op_block(int index, const float* in, int n, float* expand_out, floa
     float* d_f32 = static_cast<float*>(tmp.get(std::max({in_elems, exp_elems, dw_elems, out_elems}) * sizeof(float)));
     WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
     launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
-    enqueue_block(b, x0_, x1_, n, stream_, nullptr);
+    enqueue_block(b, view(0), x0_, x1_, n, stream_, nullptr);
     auto fetch = [&](const void* src, size_t elems, float* dst) {
         if (!dst) return;
         launch_act_to_f32(src, d_f32, elems, dtype_, stream_);

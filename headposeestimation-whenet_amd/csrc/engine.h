@@ -29,7 +29,7 @@ struct DevDw {
 };
 struct DevSe {
     int C = 0, R = 0;
-    float *w1p = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
 };
 struct DevBlock {
     BlockSpec spec;
@@ -51,6 +51,8 @@ struct LaunchRecorder {
     size_t cursor = 0;
     bool first_pass = true;
 };
+
+constexpr int MAX_LANES = 8;
 
 class Engine {
   public:
@@ -102,16 +104,29 @@ class Engine {
     void drop_graphs();
     size_t esz() const { return dtype_ == WHENET_F16 ? 2 : 4; }
 
+    struct View {          // the activation arena as seen by a sub-batch starting at some crop
+        void *x0, *x1, *e, *d, *hc;
+        float *partial, *gate;
+    };
+    View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
-    void enqueue_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
-                         LaunchRecorder* rec);
-    void enqueue_block(const DevBlock& b, const void* in, void* out, int n, hipStream_t s, LaunchRecorder* rec);
+    void enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
+                         hipStream_t s, LaunchRecorder* rec);
+    void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
+                       LaunchRecorder* rec);
+    void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
 
     int device_ = 0, dtype_ = WHENET_F32, num_cus_ = 256;
     bool use_graph_ = true;
     int pw_impl_ = 0;
+    int repeat_ = 1;
+    int lanes_ = 4;             // concurrent sub-batch chains per forward (option "lanes")
+    int min_lane_crops_ = 8;    // do not split below this many crops per chain
+    std::vector<hipStream_t> lane_streams_;
+    std::vector<hipEvent_t> join_ev_;
+    hipEvent_t fork_ev_ = nullptr;
     hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
     hipDeviceProp_t prop_{};
     int64_t params_backbone_ = 0, params_heads_ = 0;

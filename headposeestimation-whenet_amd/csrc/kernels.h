@@ -50,7 +50,7 @@ struct SeArgs {
     const float* partial;  // [n][ntiles][C]
     int ntiles;
     float inv_hw;
-    const float* w1p;      // [C][RP]  se_reduce kernel, R zero-padded to a multiple of 4
+    const float* w1t;      // [R][C]  se_reduce kernel, transposed
     const float* b1;       // [R]
     const float* w2;       // [R][C]
     const float* b2;       // [C]

@@ -110,30 +110,25 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
         return a;
     };
 
-    int ks = kpart;
-    for (; ks + (U - 1) * SK < KS; ks += U * SK) {
+    // k-loop: the (1+NT)*U loads of a group are issued before its first MFMA; steps past KS
+    // (wave-uniform) load nothing and multiply zeros.
+    for (int ks = kpart; ks < KS; ks += U * SK) {
         VT a[U];
         VT w[U][NT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const VT* wk = wp + size_t(ks + u * SK) * NTILES * 64;
+            const int k1 = ks + u * SK;
+            const VT* wk = wp + size_t(k1) * NTILES * 64;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w[u][t] = (nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
+            for (int t = 0; t < NT; ++t) w[u][t] = (k1 < KS && nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = load_a(ks + u * SK);
+        for (int u = 0; u < U; ++u) a[u] = (ks + u * SK < KS) ? load_a(ks + u * SK) : vec_zero<T>();
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (nt0 + t < NTILES) Mfma<T>::step(w[u][t], a[u], acc[t]);
-    }
-    for (; ks < KS; ks += SK) {
-        const VT a = load_a(ks);
-        const VT* wk = wp + size_t(ks) * NTILES * 64;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (nt0 + t < NTILES) Mfma<T>::step(wk[t * 64], a, acc[t]);
     }
 
     if constexpr (SK > 1) {
@@ -183,6 +178,192 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Large-M variant.  Same MFMA mapping; what changes is the data movement around it:
+//   * a workgroup owns 128 rows x NT*32 out-channels; the NT weight fragments of a k-step are
+//     shared by its 4 waves, so they are staged ONCE per workgroup into LDS (UK k-steps per
+//     stage, double-buffered, prefetched through registers while the previous stage is being
+//     multiplied) instead of being fetched by every wave from L1/L2.  The packed image is
+//     already in fragment order, so the LDS image is lane-linear: ds_read_b128, conflict-free;
+//   * NT is chosen so that, whenever the layer allows it, ONE workgroup covers all N
+//     out-channels: the activation rows are then read from HBM exactly once;
+//   * the epilogue transposes the accumulators through LDS (f32, per-wave region) so that each
+//     lane stores 16 bytes and a wave-instruction writes whole 128-byte row segments of the
+//     NHWC output (the direct form scatters 8-byte pieces: the write path, not the MFMA, was
+//     what bounded the 6x-expanding layers).
+template <typename T, int NT, bool GATE, bool RES, int ACT>
+__global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ gate,
+                                                             const T* __restrict__ res, T* __restrict__ out, int M,
+                                                             int K, int N, int KS, int NTILES, int HW, int MT,
+                                                             int NCH) {
+    constexpr int V = Vec<T>::V;
+    using VT = typename Vec<T>::type;
+    constexpr int UK = 4;                                   // k-steps per LDS stage
+    constexpr int STAGE_VECS = UK * NT * 64;                // 16-byte vectors per stage
+    constexpr int CPT = (STAGE_VECS + 255) / 256;           // staging copies per lane
+    constexpr int SW = IsF32<T>::value ? 32 : 64;           // epilogue stage width: 128-byte output rows
+    constexpr int TPS = SW / 32;                            // 32-wide tiles per epilogue stage
+    constexpr int CW = SW / 8;                              // out-channels per 16-byte output chunk
+    constexpr int SROW = SW + 4;                            // staged row pitch in floats (16-byte pad)
+    constexpr int EPI_FLOATS = 4 * 32 * SROW;
+    constexpr int W_FLOATS = 2 * STAGE_VECS * 4;
+    __shared__ __attribute__((aligned(16))) float smem[(EPI_FLOATS > W_FLOATS) ? EPI_FLOATS : W_FLOATS];
+    VT* s_w = reinterpret_cast<VT*>(smem);                  // [2][UK][NT][64 lanes]
+
+    const int id = blockIdx.x;
+    const int q = id >> 3;
+    const int nch = q % NCH;
+    const int mt = (id & 7) + 8 * (q / NCH);
+    if (mt >= MT) return;                                   // whole workgroup
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m0 = (mt * 4 + wave) * 32;
+    const int nt0 = nch * NT;
+    const int g = lane >> 5;
+    const int row = m0 + (lane & 31);
+    const bool rvalid = row < M;
+    const int rowc = rvalid ? row : (M - 1);
+
+    const T* ap = A + size_t(rowc) * K + g * V;
+    const float* gp = nullptr;
+    if constexpr (GATE) gp = gate + size_t(rowc / HW) * K + g * V;
+    const VT* wsrc = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64;
+
+    float16v acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    auto load_a = [&](int ks) -> VT {
+        VT a = vec_zero<T>();
+        if (rvalid && ks < KS && ks * 2 * V + g * V < K) {
+            a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
+            if constexpr (GATE) {
+                float f[V];
+                vec_to_float<T>(a, f);
+#pragma unroll
+                for (int i = 0; i < V; i += 4) {
+                    const float4v gv = *reinterpret_cast<const float4v*>(gp + ks * 2 * V + i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[i + j] *= gv[j];
+                }
+                a = float_to_vec<T>(f);
+            }
+        }
+        return a;
+    };
+
+    VT wreg[CPT];
+    auto fetch_w = [&](int grp) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int i = c * 256 + tid;
+            const int u = i / (NT * 64);
+            const int j = i - u * (NT * 64);
+            const int ks = grp * UK + u;
+            wreg[c] = (i < STAGE_VECS && ks < KS && nt0 + (j >> 6) < NTILES) ? wsrc[size_t(ks) * NTILES * 64 + j]
+                                                                              : vec_zero<T>();
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int i = c * 256 + tid;
+            if (i < STAGE_VECS) s_w[buf * STAGE_VECS + i] = wreg[c];
+        }
+    };
+
+    const int G = (KS + UK - 1) / UK;
+    VT areg[UK];
+    fetch_w(0);
+#pragma unroll
+    for (int u = 0; u < UK; ++u) areg[u] = load_a(u);
+    store_w(0);
+    __syncthreads();
+    for (int grp = 0; grp < G; ++grp) {
+        const bool more = grp + 1 < G;
+        VT anext[UK];
+        if (more) {
+            fetch_w(grp + 1);
+#pragma unroll
+            for (int u = 0; u < UK; ++u) anext[u] = load_a((grp + 1) * UK + u);
+        }
+        const VT* wl = s_w + (grp & 1) * STAGE_VECS + lane;
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            if (grp * UK + u < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nt0 + t < NTILES) Mfma<T>::step(wl[(u * NT + t) * 64], areg[u], acc[t]);
+            }
+        }
+        if (more) {
+            store_w((grp + 1) & 1);
+#pragma unroll
+            for (int u = 0; u < UK; ++u) areg[u] = anext[u];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias / activation in f32, LDS transpose, 16-byte row-contiguous stores ----
+    float* s_e = smem + wave * 32 * SROW;                   // aliases s_w: every wave is past the last barrier
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += TPS) {
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int t = t0 + tt;
+            if (t < NT && nt0 + t < NTILES) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int n = (nt0 + t) * 32 + 8 * qq + 4 * g;
+                    float4v y;
+                    if (n < N) {
+                        const float4v bv = *reinterpret_cast<const float4v*>(bias + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[t < NT ? t : 0][4 * qq + r] + bv[r];
+                            if constexpr (ACT == ACT_SWISH) v = swish_f<IsF32<T>::value>(v);
+                            y[r] = v;
+                        }
+                    } else {
+                        y = float4v{0.f, 0.f, 0.f, 0.f};
+                    }
+                    *reinterpret_cast<float4v*>(s_e + (lane & 31) * SROW + tt * 32 + 8 * qq + 4 * g) = y;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            const int r = idx >> 3, ch = idx & 7;
+            const int n = (nt0 + t0) * 32 + ch * CW;
+            const int rowg = m0 + r;
+            if (rowg < M && n < N && t0 + ((ch * CW) >> 5) < NT) {
+                float y[CW];
+#pragma unroll
+                for (int c4 = 0; c4 < CW; c4 += 4) {
+                    const float4v v = *reinterpret_cast<const float4v*>(s_e + r * SROW + ch * CW + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[c4 + j] = v[j];
+                }
+                if constexpr (RES) {
+                    const VT rv = *reinterpret_cast<const VT*>(res + size_t(rowg) * N + n);
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) y[j] += float(rv[j]);
+                }
+                *reinterpret_cast<VT*>(out + size_t(rowg) * N + n) = float_to_vec<T>(y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Scalar-FMA check kernel (option pw_impl=1): same operands (weights rounded to T, gate applied
 // with the same single rounding), k-ordered fmaf chain per output.  Exists so that the MFMA
 // fragment/accumulator mapping can be validated on the device against an independent kernel;
@@ -226,6 +407,15 @@ void launch_mfma(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
                        NCH);
 }
 
+template <typename T, int NT, bool GATE, bool RES, int ACT>
+void launch_tile(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
+    const int blocks = 8 * ceil_div(MT, 8) * NCH;
+    hipLaunchKernelGGL((whenet_pw_tile_kernel<T, NT, GATE, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
+                       static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, a.gate,
+                       static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES, a.HW, MT,
+                       NCH);
+}
+
 template <typename T, bool GATE, bool RES, int ACT>
 void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
     if (impl == 1) {
@@ -236,21 +426,34 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
         return;
     }
     const int cus = num_cus > 0 ? num_cus : 256;
-    // Deep contractions (K >= 320: the project convs of blocks 7-16 and the head conv, all on
-    // 14x14 / 7x7 maps) split K across the 4 waves of a workgroup.  The rule depends on the
-    // layer only, never on the batch, so a crop's result is bitwise independent of the batch
-    // it travels in (and of how a batch is sharded across GPUs).
+    // The summation order of a layer must not depend on the batch (a crop's result is bitwise
+    // independent of the batch it travels in and of how batches are split over streams/GPUs):
+    // deep contractions (K >= 320: project convs of blocks 7-16 and the head conv, all on 14x14 /
+    // 7x7 maps, i.e. few rows) ALWAYS split K over the 4 waves of a workgroup, one 32x32 tile per
+    // workgroup; everything else takes the 128-row LDS-staged kernel, whose NT only decides which
+    // wave computes which tile.
     if (a.K >= 320) {
-        launch_mfma<T, 1, 4, 4, GATE, RES, ACT>(a, ceil_div(a.M, 32), a.NTILES, stream);
+        launch_mfma<T, 1, 8, 4, GATE, RES, ACT>(a, ceil_div(a.M, 32), a.NTILES, stream);
         return;
     }
-    // NT (32-wide out-channel tiles per wave): as many as keep >= 4 workgroups per CU in
-    // flight; with fewer rows than that, favour parallelism (NT = 1).
     const int MT = ceil_div(a.M, 128);
-    const int want = 4 * cus;
-    if (MT * ceil_div(a.NTILES, 4) >= want) launch_mfma<T, 4, 2, 1, GATE, RES, ACT>(a, MT, ceil_div(a.NTILES, 4), stream);
-    else if (MT * ceil_div(a.NTILES, 2) >= want) launch_mfma<T, 2, 4, 1, GATE, RES, ACT>(a, MT, ceil_div(a.NTILES, 2), stream);
-    else launch_mfma<T, 1, 4, 1, GATE, RES, ACT>(a, MT, a.NTILES, stream);
+    int NT = 1;
+    for (int cand = (a.NTILES < 6 ? a.NTILES : 6); cand >= 1; --cand) {
+        const int nch = ceil_div(a.NTILES, cand);
+        if (MT * nch >= 2 * cus || cand == 1) {
+            NT = ceil_div(a.NTILES, nch);        // balance the chunks
+            break;
+        }
+    }
+    const int NCH = ceil_div(a.NTILES, NT);
+    switch (NT) {
+        case 1: launch_tile<T, 1, GATE, RES, ACT>(a, MT, NCH, stream); break;
+        case 2: launch_tile<T, 2, GATE, RES, ACT>(a, MT, NCH, stream); break;
+        case 3: launch_tile<T, 3, GATE, RES, ACT>(a, MT, NCH, stream); break;
+        case 4: launch_tile<T, 4, GATE, RES, ACT>(a, MT, NCH, stream); break;
+        case 5: launch_tile<T, 5, GATE, RES, ACT>(a, MT, NCH, stream); break;
+        default: launch_tile<T, 6, GATE, RES, ACT>(a, MT, NCH, stream); break;
+    }
 }
 
 template <typename T>

@@ -21,76 +21,77 @@ namespace whenet {
 namespace {
 
 template <int RP>
-__global__ __launch_bounds__(256) void whenet_se_kernel(const float* __restrict__ partial, int ntiles, float inv_hw,
-                                                        const float* __restrict__ w1p, const float* __restrict__ b1,
+__global__ __launch_bounds__(1024) void whenet_se_kernel(const float* __restrict__ partial, int ntiles, float inv_hw,
+                                                        const float* __restrict__ w1t, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ gate, int C, int R) {
     __shared__ float s_mean[1152];
-    __shared__ float s_red[4][RP];
+    constexpr int NW = 16;                      // 1024 lanes: the kernel is a pure latency chain,
+    constexpr int NTHR = NW * 64;               // so it is spread as thin as a workgroup allows
     __shared__ float s_r[RP];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
-    // squeeze: mean over the map = (sum of the depthwise kernel's tile partials) / (H*W)
+    // squeeze: mean over the map = (sum of the depthwise kernel's tile partials) / (H*W);
+    // 8 independent loads in flight per lane
     const float* pp = partial + size_t(b) * ntiles * C;
-    for (int c = tid; c < C; c += 256) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-        int i = 0;
-        for (; i + 4 <= ntiles; i += 4) {
-            t0 += pp[size_t(i) * C + c];
-            t1 += pp[size_t(i + 1) * C + c];
-            t2 += pp[size_t(i + 2) * C + c];
-            t3 += pp[size_t(i + 3) * C + c];
+    for (int c = tid; c < C; c += NTHR) {
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < ntiles; i += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u < ntiles) t[u] += pp[size_t(i + u) * C + c];
         }
-        for (; i < ntiles; ++i) t0 += pp[size_t(i) * C + c];
-        s_mean[c] = ((t0 + t1) + (t2 + t3)) * inv_hw;
+        s_mean[c] = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * inv_hw;
     }
     __syncthreads();
 
-    // reduce: r[j] = swish(b1[j] + sum_c mean[c] * W1[c][j])
-    float acc[RP];
+    // reduce: r[j] = swish(b1[j] + sum_c mean[c] * W1[c][j]).  Wave w owns outputs j = w, w+16, ..;
+    // its lanes stride over c (coalesced 256-byte rows of the transposed kernel), all loads of
+    // an output are independent, one 6-step shuffle tree per output.
+    for (int j = wave; j < RP; j += NW) {
+        float t = 0.f;
+        if (j < R) {
+            const float* wrow = w1t + size_t(j) * C;
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c0 = lane; c0 < C; c0 += 256) {
 #pragma unroll
-    for (int j = 0; j < RP; ++j) acc[j] = 0.f;
-    for (int c = tid; c < C; c += 256) {
-        const float m = s_mean[c];
-        const float4v* wr = reinterpret_cast<const float4v*>(w1p + size_t(c) * RP);
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 64 * u;
+                    if (c < C) p[u] = fmaf(s_mean[c], wrow[c], p[u]);
+                }
+            }
+            t = (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
-        for (int q = 0; q < RP / 4; ++q) {
-            const float4v v = wr[q];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaf(m, v[i], acc[4 * q + i]);
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+            t = swish_f<true>(t + b1[j]);
         }
+        if (lane == 0) s_r[j] = t;
     }
-#pragma unroll
-    for (int j = 0; j < RP; ++j) {
-        float t = acc[j];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-        if (lane == 0) s_red[wave][j] = t;
-    }
-    __syncthreads();
-    if (tid < R) s_r[tid] = swish_f<true>(((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) + b1[tid]);
     __syncthreads();
 
-    // excite: gate[c] = sigmoid(b2[c] + sum_j r[j] * W2[j][c])
-    for (int c = tid; c < C; c += 256) {
+    // excite: gate[c] = sigmoid(b2[c] + sum_j r[j] * W2[j][c]); all R loads of a channel are
+    // issued before the first FMA (R <= RP is a compile-time bound -> fully unrolled)
+    for (int c = tid; c < C; c += NTHR) {
+        float wv[RP];
+#pragma unroll
+        for (int j = 0; j < RP; ++j) wv[j] = (j < R) ? w2[size_t(j) * C + c] : 0.f;
         float t0 = b2[c], t1 = 0.f, t2 = 0.f, t3 = 0.f;
-        int j = 0;
-        for (; j + 4 <= R; j += 4) {
-            t0 = fmaf(s_r[j], w2[size_t(j) * C + c], t0);
-            t1 = fmaf(s_r[j + 1], w2[size_t(j + 1) * C + c], t1);
-            t2 = fmaf(s_r[j + 2], w2[size_t(j + 2) * C + c], t2);
-            t3 = fmaf(s_r[j + 3], w2[size_t(j + 3) * C + c], t3);
+#pragma unroll
+        for (int j = 0; j < RP; j += 4) {
+            t0 = fmaf(s_r[j], wv[j], t0);
+            t1 = fmaf(s_r[j + 1], wv[j + 1], t1);
+            t2 = fmaf(s_r[j + 2], wv[j + 2], t2);
+            t3 = fmaf(s_r[j + 3], wv[j + 3], t3);
         }
-        for (; j < R; ++j) t0 = fmaf(s_r[j], w2[size_t(j) * C + c], t0);
         gate[size_t(b) * C + c] = sigmoid_f<true>((t0 + t1) + (t2 + t3));
     }
 }
 
 template <int RP>
 void launch_rp(const SeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(whenet_se_kernel<RP>, dim3(a.n), dim3(256), 0, stream, a.partial, a.ntiles, a.inv_hw, a.w1p,
+    hipLaunchKernelGGL(whenet_se_kernel<RP>, dim3(a.n), dim3(1024), 0, stream, a.partial, a.ntiles, a.inv_hw, a.w1t,
                        a.b1, a.w2, a.b2, a.gate, a.C, a.R);
 }
 

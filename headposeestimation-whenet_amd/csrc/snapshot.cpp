@@ -197,10 +197,9 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
             const float* b2 = need(t, p + "/se_expand/bias", {cexp}).data;
             hb.se.C = int(cexp);
             hb.se.R = int(r);
-            const uint32_t rp = (r + 3) & ~3u;
-            hb.se.w1p.assign(size_t(cexp) * rp, 0.0f);
+            hb.se.w1t.resize(size_t(r) * cexp);
             for (uint32_t c = 0; c < cexp; ++c)
-                for (uint32_t j = 0; j < r; ++j) hb.se.w1p[size_t(c) * rp + j] = w1[size_t(c) * r + j];
+                for (uint32_t j = 0; j < r; ++j) hb.se.w1t[size_t(j) * cexp + c] = w1[size_t(c) * r + j];
             hb.se.b1.assign(b1, b1 + r);
             hb.se.w2.assign(w2, w2 + size_t(r) * cexp);
             hb.se.b2.assign(b2, b2 + cexp);

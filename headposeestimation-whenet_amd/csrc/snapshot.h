@@ -43,7 +43,7 @@ struct HostDw {
 
 struct HostSe {
     int C = 0, R = 0;
-    std::vector<float> w1p;          // [C][RP] (se_reduce kernel, R zero-padded to a multiple of 4)
+    std::vector<float> w1t;          // [R][C]  (se_reduce kernel transposed)
     std::vector<float> b1;           // [R]
     std::vector<float> w2;           // [R][C]  (se_expand kernel)
     std::vector<float> b2;           // [C]

@@ -148,8 +148,10 @@ def test_mfma_against_scalar_check_kernels(handle, golden):
 
 
 def test_batch_invariance_and_permutation(handle, golden):
-    """Per-crop work is independent: results are bitwise the same whatever the batch size or
-    position (this is also why the multi-GPU shard reproduces the single-GPU run exactly)."""
+    """Per-crop work is independent and every layer's launch configuration (hence its summation
+    order) is fixed by the layer, never by the batch: a crop's result is BITWISE the same
+    whatever the batch size, its position in the batch, or how the engine splits the batch over
+    its concurrent streams."""
     crops = np.concatenate([golden["crops"], synth.scene_crops(5, seed=21)])       # 13: ragged
     ypr, am, lg = handle.forward(crops)
     for i in (0, 7, 12):
@@ -157,10 +159,29 @@ def test_batch_invariance_and_permutation(handle, golden):
         assert np.array_equal(l1[0], lg[i]) and np.array_equal(y1[0], ypr[i]) and np.array_equal(a1[0], am[i])
     perm = np.random.default_rng(0).permutation(len(crops))
     yp, ap, lp = handle.forward(crops[perm])
-    assert np.array_equal(lp, lg[perm]) and np.array_equal(yp, ypr[perm])
+    assert np.array_equal(lp, lg[perm]) and np.array_equal(yp, ypr[perm]) and np.array_equal(ap, am[perm])
     for n in (2, 3, 5, 9):
         y2, _, l2 = handle.forward(crops[:n])
         assert np.array_equal(l2, lg[:n])
+    for lanes in (1, 2, 3):
+        handle.set_option("lanes", lanes)
+        handle.set_option("min_lane_crops", 2)
+        try:
+            y3, a3, l3 = handle.forward(crops)
+        finally:
+            handle.set_option("lanes", 4)
+            handle.set_option("min_lane_crops", 8)
+        assert np.array_equal(l3, lg) and np.array_equal(y3, ypr) and np.array_equal(a3, am)
+
+
+def test_shard_sized_batches_are_bitwise_identical(handle):
+    """What the multi-GPU batch shard relies on (BASELINE.json configs[3]: 64 crops per GPU):
+    a 128-crop batch and its two 64-crop halves run separately give bitwise equal results."""
+    crops = np.concatenate([synth.noise_crops(100, seed=4), synth.scene_crops(28, seed=5)])
+    ypr, am, lg = handle.forward(crops)
+    for lo in (0, 64):
+        y, a, l = handle.forward(crops[lo:lo + 64])
+        assert np.array_equal(l, lg[lo:lo + 64]) and np.array_equal(y, ypr[lo:lo + 64]) and np.array_equal(a, am[lo:lo + 64])
 
 
 def test_graph_replay_equals_eager(handle, golden):
@@ -176,12 +197,15 @@ def test_graph_replay_equals_eager(handle, golden):
 
 
 def test_submit_collect_pipeline(handle, golden):
+    """Pinned-buffer submit/collect (up to 4 in flight) returns exactly what the blocking call
+    returns for the same crops."""
     crops = golden["crops"]
-    ref, ram, rlg = handle.forward(crops)
-    tickets = [(handle.submit(crops[i:i + k]), i, k) for i, k in ((0, 1), (1, 3), (4, 4))]
-    for t, i, k in tickets:
+    parts = ((0, 1), (1, 3), (4, 4))
+    refs = [handle.forward(crops[i:i + k]) for i, k in parts]
+    tickets = [handle.submit(crops[i:i + k]) for i, k in parts]
+    for t, (i, k), (rypr, ram, rlg) in zip(tickets, parts, refs):
         ypr, am, lg = handle.collect(t, k, want_logits=True)
-        assert np.array_equal(ypr, ref[i:i + k]) and np.array_equal(am, ram[i:i + k]) and np.array_equal(lg, rlg[i:i + k])
+        assert np.array_equal(ypr, rypr) and np.array_equal(am, ram) and np.array_equal(lg, rlg)
     with pytest.raises(ValueError):
         handle.collect(12345, 1)
 

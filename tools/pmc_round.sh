@@ -1,0 +1,19 @@
+#!/bin/bash
+# PMC counter passes (separate passes; rocprofv3 --pmc must not be combined with tracing other
+# than --kernel-trace).  Usage: bash tools/pmc_round.sh <dtype> <batch>
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+DT=${1:-f16}; B=${2:-64}
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --dtype $DT --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-latency --profile-iters 1 --no-graph"
+i=0
+for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" \
+           "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAVES" \
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  rm -rf $R/gpurun_out/pmc_${DT}_b${B}_p$i
+  timeout 400 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $R/gpurun_out/pmc_${DT}_b${B}_p$i -o p -- $CMD > $R/gpurun_out/pmc_${DT}_b${B}_p$i.log 2>&1
+  echo "pmc pass $i ($PMC) exit $?"
+done
+ls $R/gpurun_out/pmc_${DT}_b${B}_p1
