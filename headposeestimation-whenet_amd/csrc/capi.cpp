@@ -170,6 +170,11 @@ int whenet_op_head(whenet_t* h, const float* in, int n, float* feat, float* logi
     return guarded(h, [&](whenet::Engine& e) { e.op_head(in, n, feat, logits, ypr, argmax); });
 }
 
+int whenet_op_tail(whenet_t* h, const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
+                   int32_t* argmax) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_tail(in, n, nblk, x_out, feat, logits, ypr, argmax); });
+}
+
 int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax) {
     return guarded(h, [&](whenet::Engine& e) { e.op_decode(logits, n, ypr, argmax); });
 }

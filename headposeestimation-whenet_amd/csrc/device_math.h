@@ -47,4 +47,19 @@ __device__ __forceinline__ typename Vec<T>::type vec_zero() {
     return v;
 }
 
+// One k-step of the transposed 1x1-conv product on the matrix cores (see pw.hip):
+//   f16: one v_mfma_f32_32x32x16_f16 (16 k);  f32: four v_mfma_f32_32x32x2_f32 (8 k, exact f32).
+template <typename T> struct Mfma;
+template <> struct Mfma<half_t> {
+    static __device__ __forceinline__ void step(const half8& w, const half8& a, float16v& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, acc, 0, 0, 0);
+    }
+};
+template <> struct Mfma<float> {
+    static __device__ __forceinline__ void step(const float4v& w, const float4v& a, float16v& acc) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], a[t], acc, 0, 0, 0);
+    }
+};
+
 }  // namespace whenet

@@ -164,6 +164,10 @@ void Engine::set_option(const std::string& key, long value) {
         pw_impl_ = int(value);
         sync();
         drop_graphs();
+    } else if (key == "tail") {
+        tail_fused_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "lanes") {
         WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "lanes must be 1..8");
         lanes_ = int(value);
@@ -193,7 +197,7 @@ void Engine::get_info(whenet_info_t* out) const {
     out->params_backbone = params_backbone_;
     out->params_heads = params_heads_;
     out->n_tensors = n_tensors_;
-    out->n_kernels_per_forward = 66;
+    out->n_kernels_per_forward = tail_fused_ ? 25 : 66;
     out->macs_per_crop = 384857312;
     out->arena_bytes = int64_t(arena_bytes_);
     out->capacity = cap_;
@@ -373,6 +377,32 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     }
 }
 
+TailArgs Engine::tail_args(const View& v, const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr,
+                           int32_t* d_amax, float* dump_x) const {
+    TailArgs a{};
+    for (int i = 0; i < nblk; ++i) {
+        const DevBlock& b = blocks_[size_t(6 + i)];
+        TailBlock& t = a.blk[i];
+        t.we = b.expand.wp;  t.be = b.expand.bias;
+        t.wd = b.dw.w;       t.bd = b.dw.bias;
+        t.w1t = b.se.w1t;    t.b1 = b.se.b1;   t.w2 = b.se.w2;   t.b2 = b.se.b2;
+        t.wp = b.project.wp; t.bp = b.project.bias;
+        t.kse = b.expand.KS; t.nte = b.expand.NTILES; t.ksp = b.project.KS; t.ntp = b.project.NTILES;
+        t.k = b.spec.k; t.s = b.spec.s; t.cin = b.spec.cin; t.cexp = b.spec.cexp(); t.cout = b.spec.cout;
+        t.h_in = b.spec.h_in; t.h_out = b.spec.h_out; t.pad = b.spec.pad_before(); t.r = b.se.R;
+        t.has_skip = b.spec.has_skip() ? 1 : 0;
+    }
+    a.nblk = nblk;
+    a.n = n;
+    a.x_in = x_in;
+    a.d_scratch = v.d;
+    a.d_stride = D_ELEMS;
+    a.wh = head_.wp;  a.bh = head_.bias;  a.ksh = head_.KS;  a.nth = head_.NTILES;
+    a.wdense = d_dense_w_;  a.bdense = d_dense_b_;
+    a.feat = feat;  a.logits = d_logits;  a.ypr = d_ypr;  a.argmax = d_amax;  a.dump_x = dump_x;
+    return a;
+}
+
 void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
                              hipStream_t s, LaunchRecorder* rec) {
     Rec R{rec, s, repeat_};
@@ -383,10 +413,18 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
           [&] { launch_stem(a, dtype_, s); });
     }
     void* cur = v.x0;
-    for (const DevBlock& b : blocks_) {
+    const size_t nlayer = tail_fused_ ? 6 : blocks_.size();
+    for (size_t i = 0; i < nlayer; ++i) {
         void* nxt = (cur == v.x0) ? v.x1 : v.x0;
-        enqueue_block(b, v, cur, nxt, n, s, rec);
+        enqueue_block(blocks_[i], v, cur, nxt, n, s, rec);
         cur = nxt;
+    }
+    if (tail_fused_) {
+        const TailArgs a = tail_args(v, cur, n, 10, nullptr, d_logits, d_ypr, d_amax, nullptr);
+        // per crop: blocks 7-16 + head + heads = 99.6 M MACs; reads 62,720*es in, the weights through L2
+        R("tail", "tail", dtype_ == WHENET_F16 ? "whenet_tail_kernel<_Float16>" : "whenet_tail_kernel<float>",
+          double(n) * (196.0 * 80.0 * es + 1020.0) + 3302000.0 * es, 2.0 * n * 99.6e6, [&] { launch_tail(a, dtype_, s); });
+        return;
     }
     {
         PwArgs a{};
@@ -729,6 +767,35 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
     if (logits) WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (ypr) WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_tail(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
+                     int32_t* argmax) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(in != nullptr && nblk >= 1 && nblk <= 10, WHENET_EINVAL, "op_tail: bad arguments");
+    ensure_capacity(n);
+    const size_t N = size_t(n);
+    const size_t in_elems = N * 196 * 80;
+    const BlockSpec& last = blocks_[size_t(6 + nblk - 1)].spec;
+    const size_t out_elems = N * last.h_out * last.h_out * last.cout;
+    TempBufs tmp;
+    float* d_f32 = static_cast<float*>(tmp.get(std::max(in_elems, out_elems) * sizeof(float)));
+    float* d_feat = static_cast<float*>(tmp.get(N * FEAT * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
+    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
+    const bool dump = x_out != nullptr;
+    WHENET_REQUIRE(dump || nblk == 10, WHENET_EINVAL, "op_tail: the head needs all 10 blocks");
+    const TailArgs a = tail_args(view(0), x0_, n, nblk, d_feat, o_logits_, o_ypr_, o_amax_, dump ? d_f32 : nullptr);
+    launch_tail(a, dtype_, stream_);
+    if (dump) {
+        WHENET_HIP_CHECK(hipMemcpyAsync(x_out, d_f32, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    } else {
+        if (feat) WHENET_HIP_CHECK(hipMemcpyAsync(feat, d_feat, N * FEAT * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        if (logits) WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        if (ypr) WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    }
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 

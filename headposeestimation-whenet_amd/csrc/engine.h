@@ -76,6 +76,7 @@ class Engine {
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
+    void op_tail(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr, int32_t* argmax);
 
     void* dev_alloc(size_t nbytes);
     void dev_free(void* p);
@@ -114,6 +115,8 @@ class Engine {
                          hipStream_t s, LaunchRecorder* rec);
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
                        LaunchRecorder* rec);
+    TailArgs tail_args(const View& v, const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr,
+                       int32_t* d_amax, float* dump_x) const;
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
@@ -122,6 +125,7 @@ class Engine {
     bool use_graph_ = true;
     int pw_impl_ = 0;
     int repeat_ = 1;
+    bool tail_fused_ = true;    // blocks 7..16 + head + heads as one launch (option "tail")
     int lanes_ = 4;             // concurrent sub-batch chains per forward (option "lanes")
     int min_lane_crops_ = 8;    // do not split below this many crops per chain
     std::vector<hipStream_t> lane_streams_;

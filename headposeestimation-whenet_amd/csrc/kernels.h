@@ -93,6 +93,33 @@ struct HeadsArgs {
 };
 void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream);
 
+// ---- tail.hip ---------------------------------------------------------------------------
+// Blocks 7..16 + head conv + GAP + Dense + decode as ONE launch, one workgroup per crop.
+struct TailBlock {
+    const void* we;  const float* be;              // expand: packed MFMA image, bias [cexp]
+    const float* wd; const float* bd;              // depthwise [k*k][cexp], bias
+    const float *w1t, *b1, *w2, *b2;               // squeeze-excite
+    const void* wp;  const float* bp;              // project: packed MFMA image, bias [cout]
+    int kse, nte, ksp, ntp;                        // k-steps / 32-wide tiles of the two GEMMs
+    int k, s, cin, cexp, cout, h_in, h_out, pad, r, has_skip;
+};
+struct TailArgs {
+    TailBlock blk[10];
+    int nblk, n;
+    const void* x_in;        // [n][14][14][80] T   (output of block 6)
+    void* d_scratch;         // per-crop depthwise-output scratch, T
+    size_t d_stride;         // elements per crop in d_scratch
+    const void* wh;  const float* bh;  int ksh, nth;   // head conv
+    const float* wdense;  const float* bdense;         // [1280][252], [252]
+    float* feat;             // [n][1280] or nullptr
+    float* logits;           // [n][252] or nullptr
+    float* ypr;              // [n][3]
+    int32_t* argmax;         // [n][3] or nullptr
+    float* dump_x;           // test hook: stop after the blocks and write X as f32 [n][HW][C]
+    int fixed_off;           // filled by the launcher
+};
+void launch_tail(const TailArgs& a, int dtype, hipStream_t stream);
+
 // ---- convert.hip ------------------------------------------------------------------------
 void launch_f32_to_act(const float* src, void* dst, size_t count, int dtype, hipStream_t stream);
 void launch_act_to_f32(const void* src, float* dst, size_t count, int dtype, hipStream_t stream);

@@ -34,19 +34,6 @@ namespace whenet {
 
 namespace {
 
-template <typename T> struct Mfma;
-template <> struct Mfma<half_t> {
-    static __device__ __forceinline__ void step(const half8& w, const half8& a, float16v& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, acc, 0, 0, 0);
-    }
-};
-template <> struct Mfma<float> {
-    static __device__ __forceinline__ void step(const float4v& w, const float4v& a, float16v& acc) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], a[t], acc, 0, 0, 0);
-    }
-};
-
 // NT  32-wide out-channel tiles per wave;  U  k-steps whose loads are issued together (software
 // pipelining: (1+NT)*U 16-byte loads in flight per lane before the first MFMA of the group);
 // SK  split-K factor: 1 = the 4 waves of a workgroup own 4 different 32-row strips,

@@ -67,7 +67,7 @@ def test_info(handle):
     i = handle.info()
     assert i.abi_version == _lib.ABI_VERSION
     assert (i.params_backbone, i.params_heads, i.n_tensors) == (4_049_564, 322_812, 315)
-    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 66
+    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward in (25, 66)
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
 
@@ -98,6 +98,41 @@ def test_head_kernels(handle, taps):
     t = tol(handle)
     assert rel_err(r["feat"], taps["head"].mean(axis=(1, 2))) < 3 * t
     assert np.abs(r["logits"] - taps["logits"]).max() < (2e-3 if handle.name == "f32" else 1.0)
+
+
+@pytest.mark.parametrize("nblk", list(range(1, 11)))
+def test_tail_megakernel_block_chain(handle, taps, nblk):
+    """The fused tail launch (blocks 7..16, one workgroup per crop), stopped after `nblk` blocks,
+    on the oracle's block-6 output: covers every phase (expand GEMM -> LDS, depthwise from LDS,
+    SE, gated project GEMM + skip) on every tail geometry (14x14 k3/k5, the stride-2 block 12,
+    7x7 k5/k3)."""
+    got = handle.op_tail(taps["b6/out"].astype(np.float32), nblk=nblk, dump=True)
+    ref = taps[f"b{6 + nblk}/out"]
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < (1e-4 if handle.name == "f32" else 6e-2), nblk
+
+
+def test_tail_megakernel_head(handle, taps):
+    r = handle.op_tail(taps["b6/out"].astype(np.float32))
+    assert rel_err(r["feat"], taps["head"].mean(axis=(1, 2))) < (1e-4 if handle.name == "f32" else 6e-2)
+    assert np.abs(r["logits"] - taps["logits"]).max() < (2e-3 if handle.name == "f32" else 1.0)
+    y, p, rr = O.decode(taps["logits"])
+    assert np.abs(r["ypr"] - np.stack([y, p, rr], 1)).max() < (F32_DEG if handle.name == "f32" else F16_DEG)
+
+
+def test_tail_fused_vs_layerwise(handle, golden):
+    """Same network, two schedules: the fused tail launch and one launch per layer."""
+    crops = golden["crops"]
+    ypr1, am1, lg1 = handle.forward(crops)
+    handle.set_option("tail", 0)
+    try:
+        ypr0, am0, lg0 = handle.forward(crops)
+    finally:
+        handle.set_option("tail", 1)
+    assert np.abs(lg1 - lg0).max() < (2e-3 if handle.name == "f32" else 0.6)
+    exp = golden["expected"]["angles"]
+    for ypr in (ypr0, ypr1):
+        assert np.abs(ypr - exp).max() <= (F32_DEG if handle.name == "f32" else F16_DEG)
 
 
 def test_decode_kernel(handle):
