@@ -171,8 +171,10 @@ int whenet_op_head(whenet_t* h, const float* in, int n, float* feat, float* logi
 }
 
 int whenet_op_tail(whenet_t* h, const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
-                   int32_t* argmax) {
-    return guarded(h, [&](whenet::Engine& e) { e.op_tail(in, n, nblk, x_out, feat, logits, ypr, argmax); });
+                   int32_t* argmax, uint64_t* timing) {
+    return guarded(h, [&](whenet::Engine& e) {
+        e.op_tail(in, n, nblk, x_out, feat, logits, ypr, argmax, reinterpret_cast<unsigned long long*>(timing));
+    });
 }
 
 int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax) {

@@ -231,7 +231,12 @@ DwPlan plan_dw(int dtype, int k, int s, int H, int Ho, int C) {
                 const double lane_use = double(Ho) * NSX * CG / (double(tiles_y) * threads);
                 const double halo = double(TH * s) * (TW * s) / (double(IH) * IW);   // <= 1
                 const double coalesce = (CV * 16 >= 64) ? 1.0 : 0.6 + 0.4 * (CV * 16) / 64.0;
-                const double score = lane_use * (0.5 + 0.5 * halo) * coalesce;
+                // occupancy: how many waves a CU can hold with this LDS footprint (160 KiB per CU)
+                int blocks_cu = int((160 * 1024) / lds);
+                if (blocks_cu > 8) blocks_cu = 8;
+                const double waves_cu = double(blocks_cu) * threads / 64.0;
+                const double occ = waves_cu >= 16.0 ? 1.0 : waves_cu / 16.0;
+                const double score = lane_use * (0.5 + 0.5 * halo) * coalesce * (0.4 + 0.6 * occ);
                 if (score > best_score + 1e-9) {
                     best_score = score;
                     best.threads = threads;

@@ -76,7 +76,8 @@ class Engine {
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
-    void op_tail(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr, int32_t* argmax);
+    void op_tail(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr, int32_t* argmax,
+                 unsigned long long* timing);
 
     void* dev_alloc(size_t nbytes);
     void dev_free(void* p);
@@ -125,7 +126,11 @@ class Engine {
     bool use_graph_ = true;
     int pw_impl_ = 0;
     int repeat_ = 1;
-    bool tail_fused_ = true;    // blocks 7..16 + head + heads as one launch (option "tail")
+    bool tail_fused_ = false;   // option "tail": blocks 7..16 + head + heads as ONE launch, one workgroup per crop
+                                // (tail.hip). Correct and tested, but a lone CU needs ~1.1 ms per crop: it only matches
+                                // the per-layer schedule at batch >= 256, so it is off by default.
+    TailBlock tail_host_[10];   // block descriptors of blocks 7..16 (host copy + device table)
+    TailBlock* d_tail_blocks_ = nullptr;    // blocks 7..16 + head + heads as one launch (option "tail")
     int lanes_ = 4;             // concurrent sub-batch chains per forward (option "lanes")
     int min_lane_crops_ = 8;    // do not split below this many crops per chain
     std::vector<hipStream_t> lane_streams_;

@@ -104,7 +104,8 @@ struct TailBlock {
     int k, s, cin, cexp, cout, h_in, h_out, pad, r, has_skip;
 };
 struct TailArgs {
-    TailBlock blk[10];
+    const TailBlock* blk;    // [10] block descriptors in DEVICE memory (built once per handle)
+    TailBlock first, last;   // host copies of blk[0] / blk[nblk-1] (geometry the launcher needs)
     int nblk, n;
     const void* x_in;        // [n][14][14][80] T   (output of block 6)
     void* d_scratch;         // per-crop depthwise-output scratch, T
@@ -115,10 +116,11 @@ struct TailArgs {
     float* logits;           // [n][252] or nullptr
     float* ypr;              // [n][3]
     int32_t* argmax;         // [n][3] or nullptr
+    unsigned long long* timing;   // debug: [96] wall-clock stamps of crop 0's phases, or nullptr
     float* dump_x;           // test hook: stop after the blocks and write X as f32 [n][HW][C]
     int fixed_off;           // filled by the launcher
 };
-void launch_tail(const TailArgs& a, int dtype, hipStream_t stream);
+void launch_tail(const TailArgs& a, const TailBlock* host_blk, int dtype, hipStream_t stream);
 
 // ---- convert.hip ------------------------------------------------------------------------
 void launch_f32_to_act(const float* src, void* dst, size_t count, int dtype, hipStream_t stream);

@@ -50,24 +50,34 @@ __global__ __launch_bounds__(1024) void whenet_se_kernel(const float* __restrict
     // reduce: r[j] = swish(b1[j] + sum_c mean[c] * W1[c][j]).  Wave w owns outputs j = w, w+16, ..;
     // its lanes stride over c (coalesced 256-byte rows of the transposed kernel), all loads of
     // an output are independent, one 6-step shuffle tree per output.
-    for (int j = wave; j < RP; j += NW) {
-        float t = 0.f;
-        if (j < R) {
-            const float* wrow = w1t + size_t(j) * C;
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int c0 = lane; c0 < C; c0 += 256) {
+    constexpr int JPW = (RP + NW - 1) / NW;          // outputs per wave (<= 3)
+    constexpr int CPL = 1152 / 64;                    // channel slots per lane (18)
+    {
+        float wv[JPW][CPL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = c0 + 64 * u;
-                    if (c < C) p[u] = fmaf(s_mean[c], wrow[c], p[u]);
-                }
+        for (int jj = 0; jj < JPW; ++jj) {
+            const int j = wave + NW * jj;
+            const float* wrow = w1t + size_t(j < R ? j : 0) * C;
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                const int c = lane + 64 * u;
+                wv[jj][u] = (j < R && c < C) ? wrow[c] : 0.f;          // all loads in flight at once
             }
-            t = (p[0] + p[1]) + (p[2] + p[3]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            const int j = wave + NW * jj;
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < CPL; ++u) {
+                const int c = lane + 64 * u;
+                p[u & 3] = fmaf((c < C) ? s_mean[c] : 0.f, wv[jj][u], p[u & 3]);
+            }
+            float t = (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-            t = swish_f<true>(t + b1[j]);
+            if (lane == 0 && j < RP) s_r[j] = (j < R) ? swish_f<true>(t + b1[j]) : 0.f;
         }
-        if (lane == 0) s_r[j] = t;
     }
     __syncthreads();
 

@@ -19,7 +19,7 @@
 //   SE  channel sums -> gate                 LDS, f32, fixed summation order
 // Weights stream from L2 in the host-packed MFMA fragment order (snapshot.h), 4 k-steps of loads
 // in flight per wave.  GEMM work is distributed as (32-row strip, 32-channel tile) tasks over
-// the 8 waves; MFMA mapping and epilogue arithmetic are those of pw.hip (transposed product).
+// the 12 waves; MFMA mapping and epilogue arithmetic are those of pw.hip (transposed product).
 // Per crop: 99.6 M MACs, 6.6 MB (f16) of weights read through L2, 62.7 KB in, 1 KB out.
 #include "device_math.h"
 #include "kernels.h"
@@ -28,24 +28,26 @@ namespace whenet {
 
 namespace {
 
-constexpr int NTHR = 512;
-constexpr int NWAVE = 8;
+constexpr int NTHR = 768;     // 12 waves: 149 VGPRs, no scratch; 1024 lanes would cap at 128 VGPRs and spill
+constexpr int NWAVE = 12;
+constexpr int DENSE_WAVES = 8;   // 1280 / 8 = 160 features per wave in the Dense phase
 constexpr int P = 7;
 constexpr int VC = 4;
-constexpr int SUM_FLOATS = 1152, RED_FLOATS = 2048;
+constexpr int SUM_FLOATS = 1152;
 
 template <typename T> struct TailCfg;
-template <> struct TailCfg<half_t> { static constexpr int CC14 = 64, CC7 = 256; };
-template <> struct TailCfg<float> { static constexpr int CC14 = 32, CC7 = 128; };
+// CC14 / CC7: expanded channels per chunk on the 14x14 / 7x7 maps; RED: strip partial sums
+// (28 x CC14 | 7 x CC7 floats); DWW: depthwise taps of a chunk (25 x CC floats)
+template <> struct TailCfg<half_t> { static constexpr int CC14 = 96, CC7 = 256, RED = 2688, DWW = 6400; };
+template <> struct TailCfg<float> { static constexpr int CC14 = 32, CC7 = 128, RED = 896, DWW = 3200; };
 
 __host__ __device__ constexpr int align16(int x) { return (x + 15) & ~15; }
 
 // ---- one (strip, tile) GEMM task: acc += sum_k W[tile][k] * act[row][k] ---------------------
-template <typename T, typename LoadA>
+template <typename T, int U, typename LoadA>
 __device__ __forceinline__ void gemm_task(float16v& acc, int KS, const typename Vec<T>::type* __restrict__ wfrag,
                                           int wstride, LoadA&& load_a) {
     using VT = typename Vec<T>::type;
-    constexpr int U = 4;
     for (int ks = 0; ks < KS; ks += U) {
         VT w[U], a[U];
 #pragma unroll
@@ -60,7 +62,7 @@ __device__ __forceinline__ void gemm_task(float16v& acc, int KS, const typename 
 // ---- depthwise taps of one chunk: E (LDS) -> D (global), per-strip channel sums -> s_red -----
 template <typename T, int K, int S>
 __device__ __forceinline__ void dw_chunk(const unsigned char* __restrict__ E, int EW, int EP, T* __restrict__ D,
-                                         const float* __restrict__ wd, const float* __restrict__ bd,
+                                         const float* __restrict__ s_dww, const float* __restrict__ bd,
                                          float* __restrict__ s_red, int Ho, int C, int c0, int ccur, int tid) {
     using VCT = T __attribute__((ext_vector_type(VC)));
     constexpr int NIX = (P - 1) * S + K;
@@ -77,12 +79,12 @@ __device__ __forceinline__ void dw_chunk(const unsigned char* __restrict__ E, in
     for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int v = 0; v < VC; ++v) acc[p][v] = 0.0f;
-#pragma unroll
+#pragma unroll 1   // one kernel row at a time: keeps this phase's register footprint small
     for (int ky = 0; ky < K; ++ky) {
         float wr[K][VC];
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-            const float4v wv = *reinterpret_cast<const float4v*>(wd + size_t(ky * K + kx) * C + c0 + cg * VC);
+            const float4v wv = *reinterpret_cast<const float4v*>(s_dww + (ky * K + kx) * ccur + cg * VC);
 #pragma unroll
             for (int v = 0; v < VC; ++v) wr[kx][v] = wv[v];
         }
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
     float* s_sum = reinterpret_cast<float*>(smem + a.fixed_off);     // [1152] channel sums -> means
     float* s_gate = s_sum + SUM_FLOATS;                                // [1152]
     float* s_r = s_gate + SUM_FLOATS;                                  // [64]
-    float* s_red = s_r + 64;                                           // [2048]
+    float* s_red = s_r + 64;                                           // [RED_FLOATS] strip partial sums
+    float* s_dww = s_red + TailCfg<T>::RED;                                 // [DWW_FLOATS] depthwise taps of the chunk
     unsigned char* X = smem;
 
     const int tid = threadIdx.x;
@@ -139,10 +142,15 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
     const int g = lane >> 5, lm = lane & 31;
     const int b = blockIdx.x;
     T* D = static_cast<T*>(a.d_scratch) + size_t(b) * a.d_stride;
+    // debug timeline (option: op_tail timing): crop 0, lane 0 stamps the 100 MHz wall clock
+    auto stamp = [&](int slot) {
+        if (a.timing != nullptr && b == 0 && tid == 0) a.timing[slot] = wall_clock64();
+    };
+    stamp(0);
 
     // ---- X <- block-7 input [196][80] from global ------------------------------------------
     {
-        const int C = a.blk[0].cin, HW = a.blk[0].h_in * a.blk[0].h_in;
+        const int C = a.first.cin, HW = a.first.h_in * a.first.h_in;
         const int pitch = C * SZ + 16, vpr = C * SZ / 16;
         const VT* src = reinterpret_cast<const VT*>(static_cast<const T*>(a.x_in) + size_t(b) * HW * C);
         for (int i = tid; i < HW * vpr; i += NTHR) {
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
     __syncthreads();
 
     for (int bi = 0; bi < a.nblk; ++bi) {
-        const TailBlock& B = a.blk[bi];
+        const TailBlock B = a.blk[bi];          // uniform: scalar loads from the device table
         const int HWi = B.h_in * B.h_in, HWo = B.h_out * B.h_out;
         const int pin = B.cin * SZ + 16, pout = B.cout * SZ + 16;
         const int EW = (B.h_out - 1) * B.s + B.k;
@@ -164,11 +172,17 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
 
         for (int i = tid; i < EW * EW * EP / 16; i += NTHR) reinterpret_cast<VT*>(E)[i] = vec_zero<T>();
         __syncthreads();
+        stamp(1 + bi * 8 + 0);
 
         // ================= phase 1: expand (MFMA) -> E, depthwise -> D, channel sums =========
         for (int c0 = 0; c0 < B.cexp; c0 += CC) {
             const int ccur = (B.cexp - c0 < CC) ? (B.cexp - c0) : CC;
             const int ntile = ccur >> 5;
+            // depthwise taps of this chunk -> LDS (consumed after the barrier below)
+            for (int i = tid; i < B.k * B.k * ccur; i += NTHR) {
+                const int tap = i / ccur, c = i - tap * ccur;
+                s_dww[i] = B.wd[size_t(tap) * B.cexp + c0 + c];
+            }
             for (int t = wave; t < nstrip_i * ntile; t += NWAVE) {
                 const int tile = t / nstrip_i, strip = t - tile * nstrip_i;
                 const int p = strip * 32 + lm;
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 const VT* wf = reinterpret_cast<const VT*>(B.we) + size_t((c0 >> 5) + tile) * 64 + lane;
-                gemm_task<T>(acc, B.kse, wf, B.nte * 64, [&](int ks) -> VT {
+                gemm_task<T, 8>(acc, B.kse, wf, B.nte * 64, [&](int ks) -> VT {
                     return valid ? *reinterpret_cast<const VT*>(xrow + size_t(ks) * 2 * V * SZ) : vec_zero<T>();
                 });
                 if (valid) {
@@ -196,10 +210,12 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
                 }
             }
             __syncthreads();
-            if (B.k == 3) dw_chunk<T, 3, 1>(E, EW, EP, D, B.wd, B.bd, s_red, B.h_out, B.cexp, c0, ccur, tid);
-            else if (B.s == 1) dw_chunk<T, 5, 1>(E, EW, EP, D, B.wd, B.bd, s_red, B.h_out, B.cexp, c0, ccur, tid);
-            else dw_chunk<T, 5, 2>(E, EW, EP, D, B.wd, B.bd, s_red, B.h_out, B.cexp, c0, ccur, tid);
+            if (c0 == 0) stamp(1 + bi * 8 + 1);
+            if (B.k == 3) dw_chunk<T, 3, 1>(E, EW, EP, D, s_dww, B.bd, s_red, B.h_out, B.cexp, c0, ccur, tid);
+            else if (B.s == 1) dw_chunk<T, 5, 1>(E, EW, EP, D, s_dww, B.bd, s_red, B.h_out, B.cexp, c0, ccur, tid);
+            else dw_chunk<T, 5, 2>(E, EW, EP, D, s_dww, B.bd, s_red, B.h_out, B.cexp, c0, ccur, tid);
             __syncthreads();
+            if (c0 == 0) stamp(1 + bi * 8 + 2);
             if (tid < ccur) {
                 const int nstrip = B.h_out * (B.h_out / P);
                 float t = 0.0f;
@@ -209,6 +225,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
         }
         __syncthreads();
 
+        stamp(1 + bi * 8 + 3);
         // ================= phase 2: squeeze-excite gate ======================================
         {
             const int C = B.cexp, R = B.r;
@@ -246,6 +263,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
             __syncthreads();
         }
 
+        stamp(1 + bi * 8 + 4);
         // ================= phase 3: project (MFMA) D*gate -> X (+skip) ========================
         for (int t = wave; t < nstrip_o * B.ntp; t += NWAVE) {
             const int tile = t / nstrip_o, strip = t - tile * nstrip_o;
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const VT* wf = reinterpret_cast<const VT*>(B.wp) + size_t(tile) * 64 + lane;
-            gemm_task<T>(acc, B.ksp, wf, B.ntp * 64, [&](int ks) -> VT {
+            gemm_task<T, 4>(acc, B.ksp, wf, B.ntp * 64, [&](int ks) -> VT {
                 if (!valid) return vec_zero<T>();
                 const VT av = *reinterpret_cast<const VT*>(drow + size_t(ks) * 2 * V);
                 float f[V];
@@ -296,10 +314,10 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
             }
         }
         __syncthreads();
+        stamp(1 + bi * 8 + 5);
     }
 
-    const TailBlock& L = a.blk[a.nblk - 1];
-    const int HWl = L.h_out * L.h_out, Cl = L.cout, pl = Cl * SZ + 16;
+    const int HWl = a.last.h_out * a.last.h_out, Cl = a.last.cout, pl = Cl * SZ + 16;
     if (a.dump_x != nullptr) {          // test hook: the block chain's output, [HW][C] as f32
         float* dst = a.dump_x + size_t(b) * HWl * Cl;
         for (int i = tid; i < HWl * Cl; i += NTHR) {
@@ -312,8 +330,8 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
     // ================= head conv (MFMA) + BN + Swish, fused GAP ===============================
     float* s_fp = reinterpret_cast<float*>(smem + align16(HWl * pl));      // [2][1280] strip partials
     float* s_feat = s_fp + 2 * FEAT;                                       // [1280]
-    float* s_part = s_feat + FEAT;                                         // [8][256]
-    float* s_logit = s_part + NWAVE * 256;                                 // [256]
+    float* s_part = s_feat + FEAT;                                         // [DENSE_WAVES][256]
+    float* s_logit = s_part + DENSE_WAVES * 256;                                 // [256]
     {
         const int nstrip = (HWl + 31) >> 5;                                // 2
         for (int t = wave; t < nstrip * a.nth; t += NWAVE) {
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const VT* wf = reinterpret_cast<const VT*>(a.wh) + size_t(tile) * 64 + lane;
-            gemm_task<T>(acc, a.ksh, wf, a.nth * 64, [&](int ks) -> VT {
+            gemm_task<T, 8>(acc, a.ksh, wf, a.nth * 64, [&](int ks) -> VT {
                 return valid ? *reinterpret_cast<const VT*>(xrow + size_t(ks) * 2 * V * SZ) : vec_zero<T>();
             });
 #pragma unroll
@@ -350,14 +368,15 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
         __syncthreads();
     }
 
+    stamp(90);
     // ================= Dense 120|66|66 (whenet.py:11-13) =========================================
     {
-        const int c_lo = wave * (FEAT / NWAVE);
+        const int c_lo = wave * (FEAT / DENSE_WAVES);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane < N_LOGITS / 4) {
+        if (wave < DENSE_WAVES && lane < N_LOGITS / 4) {
             const float* wr = a.wdense + size_t(c_lo) * N_LOGITS + lane * 4;
 #pragma unroll 8
-            for (int c = 0; c < FEAT / NWAVE; ++c) {
+            for (int c = 0; c < FEAT / DENSE_WAVES; ++c) {
                 const float f = s_feat[c_lo + c];
                 const float4v wv = *reinterpret_cast<const float4v*>(wr + size_t(c) * N_LOGITS);
 #pragma unroll
@@ -370,7 +389,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
         if (tid < N_LOGITS) {
             float t = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NWAVE; ++w) t += s_part[w * 256 + tid];
+            for (int w = 0; w < DENSE_WAVES; ++w) t += s_part[w * 256 + tid];
             t += a.bdense[tid];
             s_logit[tid] = t;
             if (a.logits != nullptr) a.logits[size_t(b) * N_LOGITS + tid] = t;
@@ -378,6 +397,7 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
         __syncthreads();
     }
 
+    stamp(91);
     // ================= decode (utils.py:7-11, whenet.py:28-33): wave h <-> head h ================
     if (wave >= 3) return;
     const int lo = (wave == 0) ? 0 : (wave == 1 ? N_YAW : N_YAW + N_PITCH);
@@ -419,11 +439,11 @@ __global__ __launch_bounds__(NTHR) void whenet_tail_kernel(TailArgs a) {
 }
 
 template <typename T>
-size_t tail_lds_bytes(const TailArgs& a, int* fixed_off) {
+size_t tail_lds_bytes(const TailArgs& a, const TailBlock* host_blk, int* fixed_off) {
     const int SZ = int(sizeof(T));
     int need = 0;
     for (int bi = 0; bi < a.nblk; ++bi) {
-        const TailBlock& B = a.blk[bi];
+        const TailBlock B = a.blk[bi];          // uniform: scalar loads from the device table
         const int HWi = B.h_in * B.h_in, HWo = B.h_out * B.h_out;
         const int EW = (B.h_out - 1) * B.s + B.k;
         const int CC = (B.h_in == 14) ? TailCfg<T>::CC14 : TailCfg<T>::CC7;
@@ -432,18 +452,18 @@ size_t tail_lds_bytes(const TailArgs& a, int* fixed_off) {
         const int e = EW * EW * (CC * SZ + 16);
         need = std::max(need, std::max(x_in + e, x_out));
     }
-    const TailBlock& L = a.blk[a.nblk - 1];
-    const int head = align16(L.h_out * L.h_out * (L.cout * SZ + 16)) + (3 * FEAT + NWAVE * 256 + 256) * 4;
+    const TailBlock& L = host_blk[a.nblk - 1];
+    const int head = align16(L.h_out * L.h_out * (L.cout * SZ + 16)) + (3 * FEAT + DENSE_WAVES * 256 + 256) * 4;
     need = std::max(need, head);
     need = align16(need);
     *fixed_off = need;
-    return size_t(need) + size_t(2 * SUM_FLOATS + 64 + RED_FLOATS) * sizeof(float);
+    return size_t(need) + size_t(2 * SUM_FLOATS + 64 + TailCfg<T>::RED + TailCfg<T>::DWW) * sizeof(float);
 }
 
 template <typename T>
-void launch_t(TailArgs a, hipStream_t stream) {
+void launch_t(TailArgs a, const TailBlock* host_blk, hipStream_t stream) {
     int fixed = 0;
-    const size_t lds = tail_lds_bytes<T>(a, &fixed);
+    const size_t lds = tail_lds_bytes<T>(a, host_blk, &fixed);
     WHENET_REQUIRE(lds <= 160 * 1024, WHENET_EINVAL, "tail kernel: LDS budget exceeded");
     a.fixed_off = fixed;
     static bool attr_set[64] = {};
@@ -460,10 +480,10 @@ void launch_t(TailArgs a, hipStream_t stream) {
 
 }  // namespace
 
-void launch_tail(const TailArgs& a, int dtype, hipStream_t stream) {
-    WHENET_REQUIRE(a.nblk >= 1 && a.nblk <= 10 && a.n >= 1, WHENET_EINVAL, "tail kernel: bad arguments");
-    if (dtype == WHENET_F16) launch_t<half_t>(a, stream);
-    else launch_t<float>(a, stream);
+void launch_tail(const TailArgs& a, const TailBlock* host_blk, int dtype, hipStream_t stream) {
+    WHENET_REQUIRE(a.nblk >= 1 && a.nblk <= 10 && a.n >= 1 && a.blk != nullptr, WHENET_EINVAL, "tail kernel: bad arguments");
+    if (dtype == WHENET_F16) launch_t<half_t>(a, host_blk, stream);
+    else launch_t<float>(a, host_blk, stream);
 }
 
 }  // namespace whenet

@@ -91,8 +91,8 @@ WHENET_API const char* whenet_last_error(const whenet_t* h);
 WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
- *          "tail" (0/1, default 1: blocks 7..16 + head + heads as ONE launch, one workgroup per
- *                  crop; 0 = one launch per layer),
+ *          "tail" (0/1, default 0: 1 = blocks 7..16 + head + heads as ONE launch, one workgroup
+ *                  per crop; 0 = one launch per layer),
  *          "lanes" (1..8, default 4: concurrent sub-batch chains per forward),
  *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
 WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
@@ -148,7 +148,7 @@ WHENET_API int whenet_op_head(whenet_t* h, const float* in, int n,
  * (1..10) blocks run and their output [n,Ho,Ho,Cout] is returned; with x_out == NULL
  * (nblk must be 10) the head runs too: feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3]. */
 WHENET_API int whenet_op_tail(whenet_t* h, const float* in, int n, int nblk, float* x_out,
-                   float* feat, float* logits, float* ypr, int32_t* argmax);
+                   float* feat, float* logits, float* ypr, int32_t* argmax, uint64_t* timing /* [96] or NULL */);
 /* decode only (whenet.py:28-33) on caller logits [n,252] -> ypr [n,3], argmax [n,3] */
 WHENET_API int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax);
 

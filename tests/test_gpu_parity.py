@@ -123,12 +123,12 @@ def test_tail_megakernel_head(handle, taps):
 def test_tail_fused_vs_layerwise(handle, golden):
     """Same network, two schedules: the fused tail launch and one launch per layer."""
     crops = golden["crops"]
-    ypr1, am1, lg1 = handle.forward(crops)
-    handle.set_option("tail", 0)
+    ypr0, am0, lg0 = handle.forward(crops)
+    handle.set_option("tail", 1)
     try:
-        ypr0, am0, lg0 = handle.forward(crops)
+        ypr1, am1, lg1 = handle.forward(crops)
     finally:
-        handle.set_option("tail", 1)
+        handle.set_option("tail", 0)
     assert np.abs(lg1 - lg0).max() < (2e-3 if handle.name == "f32" else 0.6)
     exp = golden["expected"]["angles"]
     for ypr in (ypr0, ypr1):
