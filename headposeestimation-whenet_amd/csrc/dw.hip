@@ -72,14 +72,29 @@ __global__ __launch_bounds__(256) void whenet_dw_kernel(const T* __restrict__ in
         if (pslot < NPL) {
             const T* src = in + (size_t(b) * H * H) * C + c0 + cvl * VL;
             const int npix = IH * IW;
-            for (int pix = pslot; pix < npix; pix += NPL) {
-                const int r = pix / IW;
-                const int c = pix - r * IW;
-                const int iy = iy0 + r, ix = ix0 + c;
-                VLT v = vec_zero<T>();
-                if (iy >= 0 && iy < H && ix >= 0 && ix < H)
-                    v = *reinterpret_cast<const VLT*>(src + (size_t(iy) * H + ix) * C);
-                *reinterpret_cast<VLT*>(s_tile + size_t(pix) * CC + cvl * VL) = v;
+            // (r, c) of this lane's pixel advance incrementally: one division per lane, none per load
+            int r = pslot / IW, c = pslot - r * IW;
+            const int dr = NPL / IW, dc = NPL - dr * IW;
+            // batches of 8 independent 16-byte loads in flight, then 8 LDS writes
+            for (int pix0 = pslot; pix0 < npix; pix0 += 8 * NPL) {
+                VLT v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    v[u] = vec_zero<T>();
+                    if (pix0 + u * NPL < npix && iy >= 0 && iy < H && ix >= 0 && ix < H)
+                        v[u] = *reinterpret_cast<const VLT*>(src + (size_t(iy) * H + ix) * C);
+                    r += dr;
+                    c += dc;
+                    if (c >= IW) {
+                        c -= IW;
+                        ++r;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (pix0 + u * NPL < npix)
+                        *reinterpret_cast<VLT*>(s_tile + size_t(pix0 + u * NPL) * CC + cvl * VL) = v[u];
             }
         }
     }

@@ -425,7 +425,10 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
     }
     const int MT = ceil_div(a.M, 128);
     int NT = 1;
-    for (int cand = (a.NTILES < 6 ? a.NTILES : 6); cand >= 1; --cand) {
+    // expanding layers (K << N) re-read their tiny activation rows cheaply: cap NT at 3 there so
+    // that 4 waves per SIMD stay resident (NT >= 5 needs > 170 registers)
+    const int nt_cap = (a.K * 4 <= a.N) ? 3 : 6;
+    for (int cand = (a.NTILES < nt_cap ? a.NTILES : nt_cap); cand >= 1; --cand) {
         const int nch = ceil_div(a.NTILES, cand);
         if (MT * nch >= 2 * cus || cand == 1) {
             NT = ceil_div(a.NTILES, nch);        // balance the chunks
