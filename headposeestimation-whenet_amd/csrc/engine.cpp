@@ -282,7 +282,8 @@ struct Rec {
     hipStream_t s;
     int repeat = 1;      // debug option "repeat": issue every (idempotent) launch this many times
     template <typename F>
-    void operator()(const std::string& layer, const char* kind, const char* kernel, double bytes, double flops, F&& fn) {
+    void operator()(const std::string& layer, const char* kind, const std::string& kernel, double bytes, double flops,
+                    F&& fn) {
         if (!rec) {
             for (int i = 0; i < repeat; ++i) fn();
             return;
@@ -330,7 +331,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.NTILES = b.expand.NTILES;
         a.HW = hw_in;
         a.act = ACT_SWISH;
-        R(p + "/expand", "pw", kernel_name_pw(dtype_, pw_impl_, false, false, ACT_SWISH), double(a.M) * (a.K + a.N) * es,
+        R(p + "/expand", "pw", kernel_name_pw(a, dtype_, pw_impl_, num_cus_).c_str(), double(a.M) * (a.K + a.N) * es,
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
         dw_in = v.e;
     }
@@ -365,7 +366,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.C = b.se.C;
         a.R = b.se.R;
         a.n = n;
-        R(p + "/se", "se", "whenet_se_kernel<RP>", double(n) * (a.ntiles + 1) * a.C * 4.0 + 2.0 * a.C * a.R * 4.0,
+        R(p + "/se", "se", ("whenet_se_kernel<" + std::to_string(se_padded_r(a.R)) + ">").c_str(), double(n) * (a.ntiles + 1) * a.C * 4.0 + 2.0 * a.C * a.R * 4.0,
           4.0 * n * a.C * a.R, [&] { launch_se(a, s); });
     }
     {
@@ -384,7 +385,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.NTILES = b.project.NTILES;
         a.HW = hw_out;
         a.act = ACT_NONE;
-        R(p + "/project", "pw", kernel_name_pw(dtype_, pw_impl_, true, sp.has_skip(), ACT_NONE),
+        R(p + "/project", "pw", kernel_name_pw(a, dtype_, pw_impl_, num_cus_).c_str(),
           double(a.M) * (a.K + a.N + (sp.has_skip() ? a.N : 0)) * es, 2.0 * a.M * a.K * a.N,
           [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
     }
@@ -444,7 +445,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.NTILES = head_.NTILES;
         a.HW = 49;
         a.act = ACT_SWISH;
-        R("head", "pw", kernel_name_pw(dtype_, pw_impl_, false, false, ACT_SWISH), double(a.M) * (a.K + a.N) * es,
+        R("head", "pw", kernel_name_pw(a, dtype_, pw_impl_, num_cus_).c_str(), double(a.M) * (a.K + a.N) * es,
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
     }
     {

@@ -2,6 +2,8 @@
 // on `stream` and returns; `dtype` selects the float / _Float16 instantiation.
 #pragma once
 
+#include <string>
+
 #include "common.h"
 
 namespace whenet {
@@ -128,6 +130,6 @@ void launch_act_to_f32(const void* src, float* dst, size_t count, int dtype, hip
 
 const char* kernel_name_stem(int dtype);
 const char* kernel_name_dw(int dtype, int k, int s);
-const char* kernel_name_pw(int dtype, int impl, bool gate, bool res, int act);
+std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus);
 
 }  // namespace whenet

@@ -385,6 +385,36 @@ __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restric
     }
 }
 
+struct PwChoice {
+    int kind;      // 1 = split-K kernel (whenet_pw_kernel<T,1,8,4,..>), 2 = LDS-staged tile kernel
+    int NT, NCH;
+};
+
+// The summation order of a layer must not depend on the batch (a crop's result is bitwise
+// independent of the batch it travels in and of how batches are split over streams/GPUs):
+// deep contractions (K >= 320: project convs of blocks 7-16 and the head conv, all on 14x14 /
+// 7x7 maps, i.e. few rows) ALWAYS split K over the 4 waves of a workgroup, one 32x32 tile per
+// workgroup; everything else takes the 128-row LDS-staged kernel, whose NT only decides which
+// wave computes which tile.
+PwChoice choose_pw(const PwArgs& a, int num_cus) {
+    const int cus = num_cus > 0 ? num_cus : 256;
+    if (a.K >= 320) return PwChoice{1, 1, a.NTILES};
+    // NT = as many of the layer's tiles per workgroup as possible (<= 6) while keeping >= 2
+    // workgroups per CU.  Expanding layers (K << N) re-read their tiny activation rows cheaply:
+    // NT is capped at 3 there so that 4 waves per SIMD stay resident (NT >= 5 needs > 170 registers).
+    const int MT = ceil_div(a.M, 128);
+    const int nt_cap = (a.K * 4 <= a.N) ? 3 : 6;
+    int NT = 1;
+    for (int cand = (a.NTILES < nt_cap ? a.NTILES : nt_cap); cand >= 1; --cand) {
+        const int nch = ceil_div(a.NTILES, cand);
+        if (MT * nch >= 2 * cus || cand == 1) {
+            NT = ceil_div(a.NTILES, nch);        // balance the chunks
+            break;
+        }
+    }
+    return PwChoice{2, NT, ceil_div(a.NTILES, NT)};
+}
+
 template <typename T, int NT, int U, int SK, bool GATE, bool RES, int ACT>
 void launch_mfma(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
     const int blocks = 8 * ceil_div(MT, 8) * NCH;
@@ -412,37 +442,19 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
                            static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.HW);
         return;
     }
-    const int cus = num_cus > 0 ? num_cus : 256;
-    // The summation order of a layer must not depend on the batch (a crop's result is bitwise
-    // independent of the batch it travels in and of how batches are split over streams/GPUs):
-    // deep contractions (K >= 320: project convs of blocks 7-16 and the head conv, all on 14x14 /
-    // 7x7 maps, i.e. few rows) ALWAYS split K over the 4 waves of a workgroup, one 32x32 tile per
-    // workgroup; everything else takes the 128-row LDS-staged kernel, whose NT only decides which
-    // wave computes which tile.
-    if (a.K >= 320) {
+    const PwChoice ch = choose_pw(a, num_cus);
+    if (ch.kind == 1) {
         launch_mfma<T, 1, 8, 4, GATE, RES, ACT>(a, ceil_div(a.M, 32), a.NTILES, stream);
         return;
     }
     const int MT = ceil_div(a.M, 128);
-    int NT = 1;
-    // expanding layers (K << N) re-read their tiny activation rows cheaply: cap NT at 3 there so
-    // that 4 waves per SIMD stay resident (NT >= 5 needs > 170 registers)
-    const int nt_cap = (a.K * 4 <= a.N) ? 3 : 6;
-    for (int cand = (a.NTILES < nt_cap ? a.NTILES : nt_cap); cand >= 1; --cand) {
-        const int nch = ceil_div(a.NTILES, cand);
-        if (MT * nch >= 2 * cus || cand == 1) {
-            NT = ceil_div(a.NTILES, nch);        // balance the chunks
-            break;
-        }
-    }
-    const int NCH = ceil_div(a.NTILES, NT);
-    switch (NT) {
-        case 1: launch_tile<T, 1, GATE, RES, ACT>(a, MT, NCH, stream); break;
-        case 2: launch_tile<T, 2, GATE, RES, ACT>(a, MT, NCH, stream); break;
-        case 3: launch_tile<T, 3, GATE, RES, ACT>(a, MT, NCH, stream); break;
-        case 4: launch_tile<T, 4, GATE, RES, ACT>(a, MT, NCH, stream); break;
-        case 5: launch_tile<T, 5, GATE, RES, ACT>(a, MT, NCH, stream); break;
-        default: launch_tile<T, 6, GATE, RES, ACT>(a, MT, NCH, stream); break;
+    switch (ch.NT) {
+        case 1: launch_tile<T, 1, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 2: launch_tile<T, 2, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 3: launch_tile<T, 3, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 4: launch_tile<T, 4, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 5: launch_tile<T, 5, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
+        default: launch_tile<T, 6, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
     }
 }
 
@@ -465,13 +477,20 @@ void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t st
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
-const char* kernel_name_pw(int dtype, int impl, bool gate, bool res, int act) {
-    (void)act;
-    if (impl == 1) return dtype == WHENET_F16 ? "whenet_pw_check_kernel<_Float16>" : "whenet_pw_check_kernel<float>";
-    if (dtype == WHENET_F16) return gate ? (res ? "whenet_pw_kernel<_Float16,gate,res>" : "whenet_pw_kernel<_Float16,gate>")
-                                         : "whenet_pw_kernel<_Float16,swish>";
-    return gate ? (res ? "whenet_pw_kernel<float,gate,res>" : "whenet_pw_kernel<float,gate>")
-                : "whenet_pw_kernel<float,swish>";
+std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
+    // the instantiation launch_pw() will pick, spelled as rocprofv3 prints it
+    const char* t = dtype == WHENET_F16 ? "_Float16" : "float";
+    const char* gate = a.gate ? "true" : "false";
+    const char* res = a.res ? "true" : "false";
+    char buf[96];
+    if (impl == 1) {
+        std::snprintf(buf, sizeof(buf), "whenet_pw_check_kernel<%s, %s, %s, %d>", t, gate, res, a.act);
+    } else {
+        const PwChoice ch = choose_pw(a, num_cus);
+        if (ch.kind == 1) std::snprintf(buf, sizeof(buf), "whenet_pw_kernel<%s, 1, 8, 4, %s, %s, %d>", t, gate, res, a.act);
+        else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d>", t, ch.NT, gate, res, a.act);
+    }
+    return buf;
 }
 
 }  // namespace whenet
