@@ -211,6 +211,22 @@ int whenet_dw_plan(int dtype, int index, int32_t out[12]) {
     }
 }
 
+int whenet_front_plan(int dtype, int index, int32_t out[12]) {
+    if (out == nullptr || (dtype != WHENET_F32 && dtype != WHENET_F16)) return WHENET_EINVAL;
+    try {
+        const auto blocks = whenet::make_blocks();
+        if (index < 2 || index > int(blocks.size())) return WHENET_EINVAL;
+        const whenet::BlockSpec& b = blocks[size_t(index - 1)];
+        const whenet::FrontPlan p = whenet::plan_front(dtype, b.k, b.s, b.h_in, b.h_out, b.cexp());
+        const int32_t v[12] = {256, p.CC, p.TH, p.NSX, p.tiles_x, p.tiles_y, p.chunks, p.EH, p.EW,
+                               int32_t(p.lds_bytes), p.w_off, b.cexp()};
+        std::memcpy(out, v, sizeof(v));
+        return WHENET_OK;
+    } catch (...) {
+        return WHENET_EINVAL;
+    }
+}
+
 int whenet_device_alloc(whenet_t* h, size_t nbytes, void** d_ptr) {
     if (d_ptr == nullptr) return WHENET_EINVAL;
     return guarded(h, [&](whenet::Engine& e) { *d_ptr = e.dev_alloc(nbytes); });

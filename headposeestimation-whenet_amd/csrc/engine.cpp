@@ -118,6 +118,10 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
         b.se.b2 = upload(hb.se.b2);
         b.project = upload_pw(hb.project);
         partial_per_crop_ = std::max(partial_per_crop_, size_t(b.dw.plan.ntiles()) * b.dw.C);
+        if (hb.spec.has_expand()) {
+            b.fplan = plan_front(dtype_, hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C);
+            partial_per_crop_ = std::max(partial_per_crop_, size_t(b.fplan.ntiles()) * b.dw.C);
+        }
         blocks_.push_back(b);
     }
     head_ = upload_pw(m.head);
@@ -177,6 +181,10 @@ void Engine::set_option(const std::string& key, long value) {
         pw_impl_ = int(value);
         sync();
         drop_graphs();
+    } else if (key == "fuse_front") {
+        fuse_front_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "tail") {
         tail_fused_ = value != 0;
         sync();
@@ -210,7 +218,7 @@ void Engine::get_info(whenet_info_t* out) const {
     out->params_backbone = params_backbone_;
     out->params_heads = params_heads_;
     out->n_tensors = n_tensors_;
-    out->n_kernels_per_forward = tail_fused_ ? 25 : 66;
+    out->n_kernels_per_forward = tail_fused_ ? (fuse_front_ ? 20 : 25) : (fuse_front_ ? 51 : 66);
     out->macs_per_crop = 384857312;
     out->arena_bytes = int64_t(arena_bytes_);
     out->capacity = cap_;
@@ -317,7 +325,33 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const int hw_in = sp.h_in * sp.h_in, hw_out = sp.h_out * sp.h_out;
     const int cexp = sp.cexp();
     const void* dw_in = in;
-    if (sp.has_expand()) {
+    int se_ntiles = b.dw.plan.ntiles();
+    const bool fused = fuse_front_ && sp.has_expand() && pw_impl_ == 0;
+    if (fused) {
+        FrontArgs a{};
+        a.x = in;
+        a.wep = b.expand.wp;
+        a.be = b.expand.bias;
+        a.wd = b.dw.w;
+        a.bd = b.dw.bias;
+        a.out = v.d;
+        a.partial = v.partial;
+        a.k = sp.k;
+        a.s = sp.s;
+        a.H = sp.h_in;
+        a.Ho = sp.h_out;
+        a.Cin = sp.cin;
+        a.Cexp = cexp;
+        a.pad = sp.pad_before();
+        a.KSe = b.expand.KS;
+        a.NTe = b.expand.NTILES;
+        a.n = n;
+        a.plan = b.fplan;
+        se_ntiles = b.fplan.ntiles();
+        R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
+          2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
+          [&] { launch_front(a, dtype_, s); });
+    } else if (sp.has_expand()) {
         PwArgs a{};
         a.a = in;
         a.wp = b.expand.wp;
@@ -335,7 +369,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
         dw_in = v.e;
     }
-    {
+    if (!fused) {
         DwArgs a{};
         a.in = dw_in;
         a.out = v.d;
@@ -356,7 +390,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     {
         SeArgs a{};
         a.partial = v.partial;
-        a.ntiles = b.dw.plan.ntiles();
+        a.ntiles = se_ntiles;
         a.inv_hw = 1.0f / float(hw_out);
         a.w1t = b.se.w1t;
         a.b1 = b.se.b1;

@@ -35,6 +35,7 @@ struct DevBlock {
     BlockSpec spec;
     DevPw expand;
     DevDw dw;
+    FrontPlan fplan;       // fused expand+depthwise tiling (blocks with an expand conv)
     DevSe se;
     DevPw project;
 };
@@ -126,6 +127,7 @@ class Engine {
     bool use_graph_ = true;
     int pw_impl_ = 0;
     int repeat_ = 1;
+    bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
     bool tail_fused_ = false;   // option "tail": blocks 7..16 + head + heads as ONE launch, one workgroup per crop
                                 // (tail.hip). Correct and tested, but a lone CU needs ~1.1 ms per crop: it only matches
                                 // the per-layer schedule at batch >= 256, so it is off by default.

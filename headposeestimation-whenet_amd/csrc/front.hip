@@ -1,0 +1,302 @@
+// MBConv "front": expand 1x1 conv (MFMA) + BN + Swish  ->  depthwise kxk conv + BN + Swish, ONE
+// kernel; the 6x-expanded tensor lives only in LDS.
+//
+// Reference: efficientnet 0.0.4 MBConvBlock, blocks 2..16 (/root/reference/whenet.py:8; SURVEY.md
+// Appendix B): Conv2D(in*6, 1x1, no bias) -> BN -> Swish -> DepthwiseConv2D(k, s, 'same') -> BN ->
+// Swish.  As two launches the expanded tensor is written to and re-read from HBM: 2 x 7.8 MB of
+// the 27.7 MB a crop moves (f16), plus a kernel boundary per block.
+//
+// Mapping (gfx950): workgroup = crop x chunk of CC expanded channels x output tile of TH rows x
+// 7*NSX columns (same tiling as dw.hip).  It
+//   1. zeroes its LDS tile E [(TH-1)s+k][(7*NSX-1)s+k] pixels x CC channels -- the zero halo is
+//      TF 'SAME' padding of the EXPANDED tensor (padding is zero after expand+Swish, not
+//      expand(0));
+//   2. computes the expand conv for the in-image pixels of that input tile on the matrix cores
+//      (transposed product, packed weight fragments, exactly as pw.hip; the block's input rows are
+//      read straight from global/L2 as 16-byte MFMA fragments) and writes BN+Swish'ed values into E
+//      (interior halo pixels are recomputed by the neighbouring tiles: (EH*EW)/(TH*s*7*NSX*s)
+//      extra MFMA work, free on this HBM-bound path);
+//   3. runs the depthwise taps out of E (lane = 4 channels x strip of 7 output pixels), BN+Swish,
+//      stores NHWC and the tile's channel sums for the squeeze-excite mean (fixed order).
+// HBM bytes per crop: H^2*Cin (x chunks, L2 hits) + Ho^2*Cexp written once: 13.9 MB -> the
+// "2-kernel MBConv" traffic of BASELINE.md.  Arithmetic and summation order of both convs are those
+// of pw.hip / dw.hip (the expanded activation is rounded to T in LDS exactly as it was in HBM); only
+// the grouping of the squeeze-excite partial sums follows this kernel's own tiling.
+#include "device_math.h"
+#include "kernels.h"
+
+namespace whenet {
+
+namespace {
+
+constexpr int P = 7;
+constexpr int VC = 4;
+constexpr int NTHR = 256;
+constexpr int NWAVE = 4;
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict__ x, const T* __restrict__ wep,
+                                                            const float* __restrict__ be,
+                                                            const float* __restrict__ wd,
+                                                            const float* __restrict__ bd, T* __restrict__ out,
+                                                            float* __restrict__ partial, int H, int Ho, int Cin,
+                                                            int Cexp, int pad, int KSe, int NTe, int CC, int TH,
+                                                            int NSX, int tiles_x, int EH, int EW, int w_off) {
+    constexpr int V = Vec<T>::V;
+    constexpr int SZ = int(sizeof(T));
+    using VT = typename Vec<T>::type;
+    using OT = T __attribute__((ext_vector_type(4)));
+    using VCT = OT;
+    constexpr int NIX = (P - 1) * S + K;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;                                            // [EH*EW] pixels, pitch EP
+    float* s_red = reinterpret_cast<float*>(smem);                      // aliases E after the taps
+    float* s_w = reinterpret_cast<float*>(smem + w_off);                // [K*K][CC]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, lm = lane & 31;
+    const int tile = blockIdx.x;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int c0 = blockIdx.y * CC;
+    const int ccur = (Cexp - c0 < CC) ? (Cexp - c0) : CC;
+    const int b = blockIdx.z;
+    const int EP = CC * SZ + 16;
+    const int oy0 = tyi * TH, ox0 = txi * NSX * P;
+    const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+
+    for (int i = tid; i < EH * EW * EP / 16; i += NTHR) reinterpret_cast<VT*>(E)[i] = vec_zero<T>();
+    for (int i = tid; i < K * K * ccur; i += NTHR) {
+        const int tap = i / ccur, c = i - tap * ccur;
+        s_w[tap * CC + c] = wd[size_t(tap) * Cexp + c0 + c];
+    }
+    __syncthreads();
+
+    // ---- expand (MFMA) over the in-image pixels of the input tile -> E ------------------------
+    {
+        const int iy_lo = iy0 < 0 ? 0 : iy0, ix_lo = ix0 < 0 ? 0 : ix0;
+        const int iy_hi = (iy0 + EH < H) ? iy0 + EH : H, ix_hi = (ix0 + EW < H) ? ix0 + EW : H;
+        const int RW = ix_hi - ix_lo, npx = (iy_hi - iy_lo) * RW;
+        const int nstrip = (npx + 31) >> 5, ntile = (ccur + 31) >> 5;
+        for (int t = wave; t < nstrip * ntile; t += NWAVE) {
+            const int tl = t / nstrip, strip = t - tl * nstrip;
+            const int q = strip * 32 + lm;
+            const bool valid = q < npx;
+            const int ry = valid ? q / RW : 0, rx = valid ? q - ry * RW : 0;
+            const int iy = iy_lo + ry, ix = ix_lo + rx;
+            const T* xrow = x + ((size_t(b) * H + iy) * H + ix) * Cin + g * V;
+            float16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const VT* wf = reinterpret_cast<const VT*>(wep) + size_t((c0 >> 5) + tl) * 64 + lane;
+            for (int ks = 0; ks < KSe; ks += 4) {
+                VT w[4], a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = (ks + u < KSe) ? wf[size_t(ks + u) * NTe * 64] : vec_zero<T>();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    a[u] = (valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
+                               ? *reinterpret_cast<const VT*>(xrow + size_t(ks + u) * 2 * V)
+                               : vec_zero<T>();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Mfma<T>::step(w[u], a[u], acc);
+            }
+            if (valid) {
+                unsigned char* epix = E + size_t((iy - iy0) * EW + (ix - ix0)) * EP;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int nl = tl * 32 + 8 * qq + 4 * g;
+                    if (nl < ccur) {
+                        const float4v bv = *reinterpret_cast<const float4v*>(be + c0 + nl);
+                        OT o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = T(swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[r]));
+                        *reinterpret_cast<OT*>(epix + nl * SZ) = o;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- depthwise taps out of E: lane = (4-channel group cg, strip sidx) ---------------------
+    const int CG = ccur / VC;
+    const int NPC = NTHR / CG;
+    const int cg = tid % CG;
+    const int sidx = tid / CG;
+    const int ty = sidx / NSX, sx = sidx - ty * NSX;
+    const int oy = oy0 + ty;
+    const bool lane_ok = sidx < NPC;
+    const bool active = lane_ok && (sidx < TH * NSX) && (oy < Ho);
+    float acc[P][VC];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int v = 0; v < VC; ++v) acc[p][v] = 0.0f;
+    if (active) {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            float wr[K][VC];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float4v wv = *reinterpret_cast<const float4v*>(s_w + (ky * K + kx) * CC + cg * VC);
+#pragma unroll
+                for (int v = 0; v < VC; ++v) wr[kx][v] = wv[v];
+            }
+            const unsigned char* row = E + size_t((ty * S + ky) * EW + sx * P * S) * EP + cg * VC * SZ;
+#pragma unroll
+            for (int ix = 0; ix < NIX; ++ix) {
+                const VCT xv = *reinterpret_cast<const VCT*>(row + size_t(ix) * EP);
+                float xf[VC];
+#pragma unroll
+                for (int v = 0; v < VC; ++v) xf[v] = float(xv[v]);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int d = ix - kx;
+                    if (d >= 0 && (d % S) == 0 && (d / S) < P) {
+#pragma unroll
+                        for (int v = 0; v < VC; ++v) acc[d / S][v] = fmaf(xf[v], wr[kx][v], acc[d / S][v]);
+                    }
+                }
+            }
+        }
+    }
+    float sum[VC] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const float4v bs = *reinterpret_cast<const float4v*>(bd + c0 + cg * VC);
+        T* dst = out + ((size_t(b) * Ho + oy) * Ho + (ox0 + sx * P)) * Cexp + c0 + cg * VC;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            VCT o;
+#pragma unroll
+            for (int v = 0; v < VC; ++v) {
+                const float y = swish_f<IsF32<T>::value>(acc[p][v] + bs[v]);
+                sum[v] += y;
+                o[v] = T(y);
+            }
+            *reinterpret_cast<VCT*>(dst + size_t(p) * Cexp) = o;
+        }
+    }
+    __syncthreads();                                   // every lane is done reading E
+    if (lane_ok) {
+#pragma unroll
+        for (int v = 0; v < VC; ++v) s_red[sidx * ccur + cg * VC + v] = sum[v];
+    }
+    __syncthreads();
+    if (tid < ccur) {
+        float t = 0.0f;
+        for (int s = 0; s < NPC; ++s) t += s_red[s * ccur + tid];
+        partial[(size_t(b) * gridDim.x + tile) * Cexp + c0 + tid] = t;
+    }
+}
+
+template <typename T, int K, int S>
+void launch_t(const FrontArgs& a, hipStream_t stream) {
+    const FrontPlan& p = a.plan;
+    dim3 grid(p.tiles_x * p.tiles_y, p.chunks, a.n);
+    static bool attr[64] = {};
+    int dev = 0;
+    WHENET_HIP_CHECK(hipGetDevice(&dev));
+    if (p.lds_bytes > 64 * 1024 && dev >= 0 && dev < 64 && !attr[dev]) {
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr[dev] = true;
+    }
+    hipLaunchKernelGGL((whenet_front_kernel<T, K, S>), grid, dim3(NTHR), p.lds_bytes, stream,
+                       static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
+                       static_cast<T*>(a.out), a.partial, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
+                       p.tiles_x, p.EH, p.EW, p.w_off);
+    WHENET_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void launch_ks(const FrontArgs& a, hipStream_t stream) {
+    if (a.k == 3 && a.s == 1) launch_t<T, 3, 1>(a, stream);
+    else if (a.k == 3 && a.s == 2) launch_t<T, 3, 2>(a, stream);
+    else if (a.k == 5 && a.s == 1) launch_t<T, 5, 1>(a, stream);
+    else if (a.k == 5 && a.s == 2) launch_t<T, 5, 2>(a, stream);
+    else throw Error(WHENET_EINVAL, "front: unsupported kernel/stride");
+}
+
+}  // namespace
+
+// Tile-shape search (same idea as plan_dw): chunk width CC (multiples of 32, or the whole
+// layer), TH output rows, NSX 7-pixel strips; 256 lanes; LDS <= 64 KiB.  Score = useful lanes x
+// halo efficiency (also the expand recompute factor) x occupancy.
+FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
+    const int SZ = (dtype == WHENET_F16) ? 2 : 4;
+    WHENET_REQUIRE(Cexp % VC == 0 && Ho % P == 0, WHENET_EINVAL, "front: unsupported geometry");
+    const int spr = Ho / P;
+    FrontPlan best;
+    double best_score = -1.0;
+    for (int CC = 32; CC <= 160; CC += 32) {
+        int cc = CC;
+        if (cc > Cexp) cc = Cexp;
+        if (cc != Cexp && cc % 32) continue;
+        const int CG = cc / VC;
+        if (CG > NTHR) continue;
+        const int NS = NTHR / CG;
+        for (int NSX = 1; NSX <= spr; ++NSX) {
+            if (spr % NSX) continue;
+            if (NSX > NS) break;
+            int last_th = -1;
+            for (int tiles_y = 1; tiles_y <= Ho; ++tiles_y) {
+                const int TH = ceil_div(Ho, tiles_y);
+                if (TH == last_th) continue;
+                last_th = TH;
+                if (TH * NSX > NS) continue;
+                const int TW = NSX * P;
+                const int EH = (TH - 1) * s + k, EW = (TW - 1) * s + k;
+                const int EP = cc * SZ + 16;
+                size_t tile_bytes = size_t(EH) * EW * EP;
+                const size_t red_bytes = size_t(NTHR) * VC * 4;              // [NTHR/CG][cc] floats
+                if (red_bytes > tile_bytes) tile_bytes = red_bytes;
+                const size_t w_off = (tile_bytes + 15) & ~size_t(15);
+                const size_t lds = w_off + size_t(k) * k * cc * 4;
+                if (lds > 64 * 1024) continue;
+                const int chunks = ceil_div(Cexp, cc);
+                const double lane_use = double(Ho) * NSX * CG / (double(ceil_div(Ho, TH)) * NTHR) *
+                                        (double(Cexp) / (double(chunks) * cc));
+                const double halo = double(TH * s) * (TW * s) / (double(EH) * EW);
+                int blocks_cu = int((160 * 1024) / lds);
+                if (blocks_cu > 8) blocks_cu = 8;
+                const double waves_cu = double(blocks_cu) * NTHR / 64.0;
+                const double occ = waves_cu >= 16.0 ? 1.0 : waves_cu / 16.0;
+                const double score = lane_use * (0.35 + 0.65 * halo) * (0.4 + 0.6 * occ);
+                if (score > best_score + 1e-9) {
+                    best_score = score;
+                    best.CC = cc;
+                    best.TH = TH;
+                    best.NSX = NSX;
+                    best.tiles_x = spr / NSX;
+                    best.tiles_y = ceil_div(Ho, TH);
+                    best.chunks = chunks;
+                    best.EH = EH;
+                    best.EW = EW;
+                    best.w_off = int(w_off);
+                    best.lds_bytes = lds;
+                }
+            }
+        }
+    }
+    WHENET_REQUIRE(best_score > 0, WHENET_EINVAL, "front: no tile plan fits");
+    (void)H;
+    return best;
+}
+
+void launch_front(const FrontArgs& a, int dtype, hipStream_t stream) {
+    if (dtype == WHENET_F16) launch_ks<half_t>(a, stream);
+    else launch_ks<float>(a, stream);
+}
+
+const char* kernel_name_front(int dtype, int k, int s) {
+    static const char* names[2][2][2] = {
+        {{"whenet_front_kernel<float, 3, 1>", "whenet_front_kernel<float, 3, 2>"},
+         {"whenet_front_kernel<float, 5, 1>", "whenet_front_kernel<float, 5, 2>"}},
+        {{"whenet_front_kernel<_Float16, 3, 1>", "whenet_front_kernel<_Float16, 3, 2>"},
+         {"whenet_front_kernel<_Float16, 5, 1>", "whenet_front_kernel<_Float16, 5, 2>"}}};
+    return names[dtype == WHENET_F16][k == 5][s == 2];
+}
+
+}  // namespace whenet

@@ -95,6 +95,32 @@ struct HeadsArgs {
 };
 void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream);
 
+// ---- front.hip --------------------------------------------------------------------------
+// expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).
+struct FrontPlan {
+    int CC = 32;           // expanded channels per workgroup
+    int TH = 1, NSX = 1;   // output tile: TH rows x 7*NSX columns
+    int tiles_x = 1, tiles_y = 1, chunks = 1;
+    int EH = 0, EW = 0;    // LDS tile of the expanded input (with halo)
+    int w_off = 0;         // byte offset of the depthwise taps in LDS
+    size_t lds_bytes = 0;
+    int ntiles() const { return tiles_x * tiles_y; }
+};
+FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp);
+struct FrontArgs {
+    const void* x;         // [n,H,H,Cin] T  block input
+    const void* wep;       // packed expand weights (MFMA fragment order)
+    const float* be;       // [Cexp]
+    const float* wd;       // [k*k][Cexp]
+    const float* bd;       // [Cexp]
+    void* out;             // [n,Ho,Ho,Cexp] T
+    float* partial;        // [n][ntiles][Cexp]
+    int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
+    FrontPlan plan;
+};
+void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
+const char* kernel_name_front(int dtype, int k, int s);
+
 // ---- tail.hip ---------------------------------------------------------------------------
 // Blocks 7..16 + head conv + GAP + Dense + decode as ONE launch, one workgroup per crop.
 struct TailBlock {

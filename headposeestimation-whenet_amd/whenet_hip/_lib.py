@@ -54,6 +54,7 @@ _PROTOS = {
     "whenet_op_decode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "whenet_block_spec": (C.c_int, [C.c_int, C.POINTER(C.c_int32 * 8)]),
     "whenet_dw_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32 * 12)]),
+    "whenet_front_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32 * 12)]),
     "whenet_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "whenet_device_free": (C.c_int, [_P, _P]),
     "whenet_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -277,4 +278,14 @@ def dw_plan(dtype: int, index: int) -> dict:
     if rc != OK:
         raise_for(rc, f"whenet_dw_plan({dtype},{index})")
     keys = ("threads", "CV", "TH", "NSX", "tiles_x", "tiles_y", "chunks", "IH", "IW", "lds_bytes", "pad", "C")
+    return dict(zip(keys, out))
+
+
+def front_plan(dtype: int, index: int) -> dict:
+    lib = load()
+    out = (C.c_int32 * 12)()
+    rc = lib.whenet_front_plan(dtype, index, C.byref(out))
+    if rc != OK:
+        raise_for(rc, f"whenet_front_plan({dtype},{index})")
+    keys = ("threads", "CC", "TH", "NSX", "tiles_x", "tiles_y", "chunks", "EH", "EW", "lds_bytes", "w_off", "C")
     return dict(zip(keys, out))

@@ -91,6 +91,8 @@ WHENET_API const char* whenet_last_error(const whenet_t* h);
 WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
+ *          "fuse_front" (0/1, default 1: expand 1x1 + depthwise as ONE kernel per block, the
+ *                  expanded tensor stays in LDS; 0 = two launches through HBM),
  *          "tail" (0/1, default 0: 1 = blocks 7..16 + head + heads as ONE launch, one workgroup
  *                  per crop; 0 = one launch per layer),
  *          "lanes" (1..8, default 4: concurrent sub-batch chains per forward),
@@ -160,6 +162,10 @@ WHENET_API int whenet_block_spec(int index, int32_t out[8]);
 /* the depthwise tile plan of block `index` for `dtype` (pure host logic; no GPU needed):
  * out = {threads, CV, TH, NSX, tiles_x, tiles_y, chunks, IH, IW, lds_bytes, pad_before, C} */
 WHENET_API int whenet_dw_plan(int dtype, int index, int32_t out[12]);
+
+/* the fused expand+depthwise tile plan of block `index` (2..16) for `dtype` (pure host logic):
+ * out = {threads, CC, TH, NSX, tiles_x, tiles_y, chunks, EH, EW, lds_bytes, w_off, Cexp} */
+WHENET_API int whenet_front_plan(int dtype, int index, int32_t out[12]);
 
 /* raw device-memory helpers so a host without torch can use the device-pointer form */
 WHENET_API int whenet_device_alloc(whenet_t* h, size_t nbytes, void** d_ptr);
