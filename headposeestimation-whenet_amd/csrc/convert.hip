@@ -20,12 +20,19 @@ __global__ __launch_bounds__(256) void whenet_act_to_f32_kernel(const T* __restr
         dst[i] = float(src[i]);
 }
 
+__global__ void whenet_empty_kernel() {}
+
 inline unsigned grid_for(size_t count) {
     size_t g = (count + 255) / 256;
     return unsigned(g > 4096 ? 4096 : (g ? g : 1));
 }
 
 }  // namespace
+
+void launch_empty(hipStream_t stream) {
+    hipLaunchKernelGGL(whenet_empty_kernel, dim3(1), dim3(64), 0, stream);
+    WHENET_HIP_CHECK(hipGetLastError());
+}
 
 void launch_f32_to_act(const float* src, void* dst, size_t count, int dtype, hipStream_t stream) {
     if (dtype == WHENET_F16)

@@ -303,14 +303,12 @@ struct Rec {
             e.kernel = kernel;
             e.bytes = bytes;
             e.flops = flops;
-            WHENET_HIP_CHECK(hipEventCreate(&e.start));
             WHENET_HIP_CHECK(hipEventCreate(&e.stop));
             rec->entries.push_back(e);
         }
         LaunchRecorder::Entry& e = rec->entries.at(rec->cursor++);
-        WHENET_HIP_CHECK(hipEventRecord(e.start, s));
         fn();
-        WHENET_HIP_CHECK(hipEventRecord(e.stop, s));
+        WHENET_HIP_CHECK(hipEventRecord(e.stop, s));     // ONE event between consecutive launches
     }
 };
 
@@ -674,42 +672,77 @@ void Engine::collect(int ticket, float* ypr, int32_t* argmax, float* logits) {
     slot->busy = false;
 }
 
+// Per-launch timing of the forward AS THE TIMED PATH RUNS IT: the same sub-batch chains on the
+// same streams, concurrently, launched eagerly with one HIP event recorded on the chain's stream
+// between consecutive kernels (a launch's time = previous event -> its own event, i.e. kernel plus
+// the boundary in front of it).  Entries: one per launch of a chain; durations averaged over the
+// chains and the iterations; bytes / flops are those of ONE chain's launch (its sub-batch).
 int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap) {
     DeviceGuard guard(device_);
     WHENET_REQUIRE(d_crops != nullptr && iters >= 1, WHENET_EINVAL, "profile: bad arguments");
     ensure_capacity(n);
-    LaunchRecorder rec;
+    int lanes = lanes_;
+    while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
+    std::vector<LaunchRecorder> recs;
+    recs.resize(size_t(lanes));
     struct Cleanup {
-        LaunchRecorder& r;
+        std::vector<LaunchRecorder>& r;
         ~Cleanup() {
-            for (auto& e : r.entries) {
-                if (e.start) (void)hipEventDestroy(e.start);
-                if (e.stop) (void)hipEventDestroy(e.stop);
+            for (auto& lr : r) {
+                if (lr.start) (void)hipEventDestroy(lr.start);
+                for (auto& e : lr.entries)
+                    if (e.stop) (void)hipEventDestroy(e.stop);
             }
         }
-    } cleanup{rec};
+    } cleanup{recs};
+    for (auto& lr : recs) WHENET_HIP_CHECK(hipEventCreate(&lr.start));
     // one untimed eager pass so that lazy code-object loading does not land in the numbers
     enqueue_forward(view(0), d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, nullptr);
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
     for (int it = 0; it < iters; ++it) {
-        rec.cursor = 0;
-        enqueue_forward(view(0), d_crops, n, o_ypr_, o_amax_, o_logits_, stream_, &rec);
-        rec.first_pass = false;
+        WHENET_HIP_CHECK(hipEventRecord(fork_ev_, stream_));
+        int off = 0;
+        for (int i = 0; i < lanes; ++i) {
+            const int cnt = n / lanes + (i < n % lanes ? 1 : 0);
+            hipStream_t st = (i == 0) ? stream_ : lane_streams_[size_t(i - 1)];
+            if (i > 0) WHENET_HIP_CHECK(hipStreamWaitEvent(st, fork_ev_, 0));
+            LaunchRecorder& lr = recs[size_t(i)];
+            lr.cursor = 0;
+            WHENET_HIP_CHECK(hipEventRecord(lr.start, st));
+            enqueue_forward(view(off), d_crops + size_t(off) * IN_BYTES, cnt, o_ypr_ + size_t(off) * 3,
+                            o_amax_ + size_t(off) * 3, o_logits_ + size_t(off) * N_LOGITS, st, &lr);
+            {   // calibration entry: an empty kernel timed the same way = the boundary + event cost
+                Rec R{&lr, st, 1};
+                R("(boundary)", "calib", "whenet_empty_kernel", 0.0, 0.0, [&] { launch_empty(st); });
+            }
+            lr.first_pass = false;
+            if (i > 0) {
+                WHENET_HIP_CHECK(hipEventRecord(join_ev_[size_t(i - 1)], st));
+                WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, join_ev_[size_t(i - 1)], 0));
+            }
+            off += cnt;
+        }
         WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-        for (auto& e : rec.entries) {
-            float ms = 0.f;
-            WHENET_HIP_CHECK(hipEventElapsedTime(&ms, e.start, e.stop));
-            e.total_ms += ms;
+        for (auto& lr : recs) {
+            hipEvent_t prev = lr.start;
+            for (auto& e : lr.entries) {
+                float ms = 0.f;
+                WHENET_HIP_CHECK(hipEventElapsedTime(&ms, prev, e.stop));
+                e.total_ms += ms;
+                prev = e.stop;
+            }
         }
     }
-    const int count = int(rec.entries.size());
+    const int count = int(recs[0].entries.size());
     for (int i = 0; i < count && i < cap && stats; ++i) {
-        const auto& e = rec.entries[size_t(i)];
+        const auto& e = recs[0].entries[size_t(i)];
+        double tot = 0;
+        for (auto& lr : recs) tot += lr.entries[size_t(i)].total_ms;
         whenet_launch_stat_t& o = stats[i];
         copy_name(o.layer, sizeof(o.layer), e.layer);
         copy_name(o.kind, sizeof(o.kind), e.kind);
         copy_name(o.kernel, sizeof(o.kernel), e.kernel);
-        o.avg_us = e.total_ms * 1000.0 / iters;
+        o.avg_us = tot * 1000.0 / (double(iters) * lanes);
         o.alg_bytes = e.bytes;
         o.alg_flops = e.flops;
     }

@@ -45,10 +45,11 @@ struct LaunchRecorder {
     struct Entry {
         std::string layer, kind, kernel;
         double bytes = 0, flops = 0;
-        hipEvent_t start = nullptr, stop = nullptr;
-        double total_ms = 0;
+        hipEvent_t stop = nullptr;      // recorded right after the launch; the previous entry's stop
+        double total_ms = 0;             // (or the chain's start event) is this launch's start
     };
     std::vector<Entry> entries;
+    hipEvent_t start = nullptr;          // recorded on the chain's stream before its first launch
     size_t cursor = 0;
     bool first_pass = true;
 };

@@ -151,6 +151,7 @@ struct TailArgs {
 void launch_tail(const TailArgs& a, const TailBlock* host_blk, int dtype, hipStream_t stream);
 
 // ---- convert.hip ------------------------------------------------------------------------
+void launch_empty(hipStream_t stream);   // boundary calibration for whenet_profile()
 void launch_f32_to_act(const float* src, void* dst, size_t count, int dtype, hipStream_t stream);
 void launch_act_to_f32(const void* src, float* dst, size_t count, int dtype, hipStream_t stream);
 

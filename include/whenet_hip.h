@@ -75,7 +75,7 @@ typedef struct whenet_launch_stat {
     char    layer[32];          /* e.g. "b3/dw", "b3/project", "stem", "heads"              */
     char    kind[16];           /* stem | pw | dw | se | heads                              */
     char    kernel[64];         /* kernel symbol family, matches rocprofv3's kernel name    */
-    double  avg_us;             /* mean duration over the profiled iterations (HIP events)  */
+    double  avg_us;             /* mean duration over chains x iterations (HIP events)        */
     double  alg_bytes;          /* algorithmic bytes of this launch: in + out (+skip) once  */
     double  alg_flops;          /* 2 * MACs of this launch                                   */
 } whenet_launch_stat_t;
@@ -124,9 +124,12 @@ WHENET_API int whenet_sync(whenet_t* h);
 WHENET_API int whenet_submit_u8(whenet_t* h, const uint8_t* crops, int n, int* ticket);
 WHENET_API int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits);
 
-/* ---- measurement: run `iters` eager forwards of `n` device-resident crops with a HIP
- * event pair around every kernel launch (on the stream the kernels run on).  Fills up to
- * `cap` entries, one per launch of a forward in launch order; *count = launches/forward. */
+/* ---- measurement: run `iters` eager forwards of `n` device-resident crops exactly as the
+ * timed path runs them (same concurrent sub-batch chains, same streams) with ONE HIP event
+ * recorded on the chain's stream between consecutive kernel launches; a launch's time is
+ * previous event -> its own event.  Fills up to `cap` entries, one per launch of a chain in
+ * launch order, averaged over chains and iterations; alg_bytes / alg_flops are those of one
+ * chain's launch (its sub-batch).  *count = launches per chain. */
 WHENET_API int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int iters,
                    whenet_launch_stat_t* stats, int cap, int* count);
 

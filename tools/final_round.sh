@@ -1,0 +1,17 @@
+#!/bin/bash
+# End-of-round evidence run (on the GPU box): full GPU test suite, default bench, rocprofv3 stats of
+# the SAME bench command, PMC passes for the HBM traffic.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out/final
+timeout 900 python -m pytest tests -m gpu -q --tb=short > $R/gpurun_out/final/pytest_gpu.txt 2>&1; echo "pytest exit $?"; tail -3 $R/gpurun_out/final/pytest_gpu.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/final/smoke.txt 2>&1; echo "smoke exit $?"; tail -3 $R/gpurun_out/final/smoke.txt
+timeout 600 python bench.py --dump-layers $R/gpurun_out/final/layers_default.json > $R/gpurun_out/final/bench_default.json 2> $R/gpurun_out/final/bench_default.err; echo "bench exit $?"
+timeout 300 python bench.py --dtype f32 --no-cpu-baseline --no-latency > $R/gpurun_out/final/bench_f32_b64.json 2>/dev/null
+timeout 300 python bench.py --batch 512 --no-cpu-baseline --no-latency > $R/gpurun_out/final/bench_f16_b512.json 2>/dev/null
+timeout 300 python bench.py --batch 8 --no-cpu-baseline --no-latency > $R/gpurun_out/final/bench_f16_b8.json 2>/dev/null
+timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-latency > $R/gpurun_out/final/bench_f16_b1.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/final/rocprof_stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -o bench -- python $R/bench.py --no-cpu-baseline --no-latency > $R/gpurun_out/final/rocprof_bench.json 2>/dev/null; echo "rocprof exit $?"
+cd $R && bash tools/pmc_round.sh f16 64 > $R/gpurun_out/final/pmc.log 2>&1; echo "pmc exit $?"
+python tools/gpu_diag.py --quick > $R/gpurun_out/final/diag.txt 2>&1; echo "diag exit $?"

@@ -6,6 +6,6 @@ python - <<PY
 import json
 for l in open("gpurun_out/bench_$1_b$2_l$3.txt"):
     if l.startswith("{"):
-        d=json.loads(l); print("$cfg", round(d["value"]), "crops/s", round(d["ms_per_step"],3), "ms/step; sum kernels", round(d["roofline"]["sum_kernel_us_per_step"]), "us")
+        d=json.loads(l); print("$cfg", round(d["value"]), "crops/s", round(d["ms_per_step"],3), "ms/step; chain", round(d["roofline"]["chain_us_per_step"]), "us")
 PY
 done

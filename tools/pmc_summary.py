@@ -1,45 +1,89 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSVs (one directory per pass) per kernel launch of ONE forward.
-usage: pmc_summary.py gpurun_out/pmc_f16_b64_p   (prefix; passes _p1.._pN are merged)"""
+"""Summarise rocprofv3 --pmc CSVs (one directory per pass, prefix + 1..N) per kernel NAME: averages
+over every dispatch of the run (the timed region and the profile pass launch the same sub-batch
+geometry).  usage: pmc_summary.py gpurun_out/pmc_f16_b64_p [traffic.json]"""
 import csv
 import glob
+import json
+import re
+import subprocess
 import sys
-from collections import defaultdict, OrderedDict
+from collections import defaultdict
 
 prefix = sys.argv[1]
-per = OrderedDict()      # dispatch order key -> {counter: value}
+CXXFILT = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+_cache = {}
+
+
+def demangle_whenet(n):
+    """rocprofv3 / llvm-cxxfilt leave the _Float16 instantiations mangled (DF16_): decode the
+    simple template argument lists of this library's kernels by hand."""
+    m = re.search(r"\d+(whenet_[a-z_]+?)I((?:DF16_|f|L[ib]\d+E)+)E", n)
+    if not m:
+        return None
+    args = []
+    for tok in re.findall(r"DF16_|f|L[ib]\d+E", m.group(2)):
+        if tok == "DF16_":
+            args.append("_Float16")
+        elif tok == "f":
+            args.append("float")
+        elif tok[1] == "b":
+            args.append("true" if tok[2:-1] == "1" else "false")
+        else:
+            args.append(tok[2:-1])
+    return f"{m.group(1)}<{', '.join(args)}>"
+
+
+def short(n):
+    if n not in _cache:
+        d = demangle_whenet(n) if n.startswith("_Z") else None
+        if d is None:
+            m = re.search(r"(whenet_\w+(<[^(]*>)?)", n)
+            d = m.group(1) if m else n[:60]
+        _cache[n] = d
+    return _cache[n]
+
+
+agg = defaultdict(lambda: {"n": defaultdict(int), "c": defaultdict(float), "t": 0.0, "tn": 0})
 for d in sorted(glob.glob(prefix + "[0-9]")):
     f = glob.glob(d + "/*counter_collection.csv")
     if not f:
         continue
-    rows = [r for r in csv.DictReader(open(f[0])) if "whenet" in r["Kernel_Name"]]
-    # group by dispatch id
-    disp = OrderedDict()
-    for r in rows:
-        k = int(r["Dispatch_Id"])
-        e = disp.setdefault(k, {"name": r["Kernel_Name"], "grid": r["Grid_Size"], "t": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "c": {}})
-        e["c"][r["Counter_Name"]] = float(r["Counter_Value"])
-    keys = sorted(disp)
-    # last complete forward = last 66 whenet dispatches that start with a stem kernel
-    stems = [i for i, k in enumerate(keys) if "stem" in disp[k]["name"] and i + 66 <= len(keys)]
-    i0 = stems[-1]
-    for j, k in enumerate(keys[i0:i0 + 66]):
-        e = per.setdefault(j, {"name": disp[k]["name"], "grid": disp[k]["grid"], "c": {}, "t": disp[k]["t"]})
-        e["c"].update(disp[k]["c"])
+    seen = set()
+    for r in csv.DictReader(open(f[0])):
+        if "whenet" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        a = agg[k]
+        a["c"][r["Counter_Name"]] += float(r["Counter_Value"])
+        a["n"][r["Counter_Name"]] += 1
+        key = (d, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            a["t"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            a["tn"] += 1
 
 
-def short(n):
-    n = n.split("whenet_")[1] if "whenet_" in n else n
-    return n.split("(")[0][:44]
+def avg(a, name):
+    return a["c"][name] / a["n"][name] if a["n"][name] else 0.0
 
 
-print(f"{'kernel':46s}{'us':>7s} {'busy%':>6s} {'valu%':>6s} {'lds%':>5s} {'wait%':>6s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'L2hit%':>6s} {'valu/wv':>8s} {'vmemRD/wv':>9s}")
-for j, e in per.items():
-    c = defaultdict(float, e["c"])
-    wc = c["SQ_WAVE_CYCLES"] or 1
-    busy = c["SQ_BUSY_CYCLES"]
-    waves = c["SQ_WAVES"] or 1
-    hit, miss = c["TCC_HIT_sum"], c["TCC_MISS_sum"]
-    print(f"{short(e['name']):46s}{e['t']:7.1f} {100 * c['SQ_ACTIVE_INST_ANY'] / wc:6.1f} {100 * c['SQ_ACTIVE_INST_VALU'] / wc:6.1f} "
-          f"{100 * c['SQ_ACTIVE_INST_LDS'] / wc:5.1f} {100 * c['SQ_WAIT_ANY'] / wc:6.1f} {100 * c['SQ_LDS_BANK_CONFLICT'] / (c['SQ_ACTIVE_INST_LDS'] or 1):8.1f} "
-          f"{2 * c['FETCH_SIZE'] / 1024:8.2f} {c['WRITE_SIZE'] / 1024:8.2f} {100 * hit / ((hit + miss) or 1):6.1f} {c['SQ_INSTS_VALU'] / waves:8.0f} {c['SQ_INSTS_VMEM_RD'] / waves:9.1f}")
+print(f"{'kernel':52s}{'us':>7s} {'act%':>6s} {'valu%':>6s} {'lds%':>5s} {'wait%':>6s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'L2hit%':>6s} {'valu/wv':>8s} {'vmemRD/wv':>9s}")
+out = {}
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"]):
+    wc = avg(a, "SQ_WAVE_CYCLES") or 1
+    waves = avg(a, "SQ_WAVES") or 1
+    hit, miss = avg(a, "TCC_HIT_sum"), avg(a, "TCC_MISS_sum")
+    fetch = 2 * avg(a, "FETCH_SIZE") * 1024       # gfx950: FETCH_SIZE tallies 64 B per 128-B request on 16-B/lane streams
+    write = avg(a, "WRITE_SIZE") * 1024
+    print(f"{k:52s}{a['t'] / max(a['tn'], 1):7.1f} {100 * avg(a, 'SQ_ACTIVE_INST_ANY') / wc:6.1f} {100 * avg(a, 'SQ_ACTIVE_INST_VALU') / wc:6.1f} "
+          f"{100 * avg(a, 'SQ_ACTIVE_INST_LDS') / wc:5.1f} {100 * avg(a, 'SQ_WAIT_ANY') / wc:6.1f} "
+          f"{100 * avg(a, 'SQ_LDS_BANK_CONFLICT') / (avg(a, 'SQ_ACTIVE_INST_LDS') or 1):8.1f} {fetch / 1e6:8.2f} {write / 1e6:8.2f} "
+          f"{100 * hit / ((hit + miss) or 1):6.1f} {avg(a, 'SQ_INSTS_VALU') / waves:8.0f} {avg(a, 'SQ_INSTS_VMEM_RD') / waves:9.1f}")
+    out[k] = {"dispatches_seen": a["tn"], "avg_us_under_pmc": a["t"] / max(a["tn"], 1), "hbm_bytes_per_launch": fetch + write,
+              "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write}
+if len(sys.argv) > 2:
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 "
+                       "(MI355X_MICROARCH.md HBM section: 64 B tallied per 128-B request on 16-B/lane streams; consistent "
+                       "here with the known read volumes of the expand and depthwise kernels); averages per dispatch",
+               "kernels": out}, open(sys.argv[2], "w"), indent=1)
