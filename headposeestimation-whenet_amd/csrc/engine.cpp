@@ -161,7 +161,7 @@ Engine::~Engine() {
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, in_u8_, o_ypr_, o_amax_, o_logits_};
+    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, se_counter_, in_u8_, o_ypr_, o_amax_, o_logits_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
@@ -179,6 +179,10 @@ void Engine::set_option(const std::string& key, long value) {
     } else if (key == "pw_impl") {
         WHENET_REQUIRE(value == 0 || value == 1, WHENET_EINVAL, "pw_impl must be 0 (MFMA) or 1 (check kernel)");
         pw_impl_ = int(value);
+        sync();
+        drop_graphs();
+    } else if (key == "fuse_se") {
+        fuse_se_ = value != 0;
         sync();
         drop_graphs();
     } else if (key == "fuse_front") {
@@ -218,7 +222,7 @@ void Engine::get_info(whenet_info_t* out) const {
     out->params_backbone = params_backbone_;
     out->params_heads = params_heads_;
     out->n_tensors = n_tensors_;
-    out->n_kernels_per_forward = tail_fused_ ? (fuse_front_ ? 20 : 25) : (fuse_front_ ? 51 : 66);
+    out->n_kernels_per_forward = tail_fused_ ? (fuse_front_ ? 20 : 25) : (fuse_front_ ? (fuse_se_ ? 36 : 51) : 66);
     out->macs_per_crop = 384857312;
     out->arena_bytes = int64_t(arena_bytes_);
     out->capacity = cap_;
@@ -237,7 +241,7 @@ void Engine::drop_graphs() {
 
 void Engine::release_arena() {
     void** arena[] = {&x0_, &x1_, &e_, &d_, &hc_, reinterpret_cast<void**>(&partial_), reinterpret_cast<void**>(&gate_),
-                      reinterpret_cast<void**>(&in_u8_), reinterpret_cast<void**>(&o_ypr_),
+                      reinterpret_cast<void**>(&se_counter_), reinterpret_cast<void**>(&in_u8_), reinterpret_cast<void**>(&o_ypr_),
                       reinterpret_cast<void**>(&o_amax_), reinterpret_cast<void**>(&o_logits_)};
     for (void** p : arena) {
         if (*p) (void)hipFree(*p);
@@ -272,6 +276,8 @@ void Engine::ensure_capacity(int n) {
     hc_ = alloc(N * HC_ELEMS * es);
     partial_ = static_cast<float*>(alloc(N * partial_per_crop_ * sizeof(float)));
     gate_ = static_cast<float*>(alloc(N * 1152 * sizeof(float)));
+    se_counter_ = static_cast<int*>(alloc(N * sizeof(int)));
+    WHENET_HIP_CHECK(hipMemset(se_counter_, 0, N * sizeof(int)));
     in_u8_ = static_cast<uint8_t*>(alloc(N * IN_BYTES));
     o_ypr_ = static_cast<float*>(alloc(N * 3 * sizeof(float)));
     o_amax_ = static_cast<int32_t*>(alloc(N * 3 * sizeof(int32_t)));
@@ -346,6 +352,15 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.n = n;
         a.plan = b.fplan;
         se_ntiles = b.fplan.ntiles();
+        if (fuse_se_) {
+            a.se.counter = v.counter;
+            a.se.w1t = b.se.w1t;
+            a.se.b1 = b.se.b1;
+            a.se.w2 = b.se.w2;
+            a.se.b2 = b.se.b2;
+            a.se.gate = v.gate;
+            a.se.R = b.se.R;
+        }
         R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
           [&] { launch_front(a, dtype_, s); });
@@ -385,7 +400,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         R(p + "/dw", "dw", kernel_name_dw(dtype_, sp.k, sp.s), double(n) * (hw_in + hw_out) * cexp * es,
           2.0 * n * hw_out * sp.k * sp.k * cexp, [&] { launch_dw(a, dtype_, s); });
     }
-    {
+    if (!(fused && fuse_se_)) {
         SeArgs a{};
         a.partial = v.partial;
         a.ntiles = se_ntiles;
@@ -505,6 +520,7 @@ Engine::View Engine::view(int crop_off) const {
     v.hc = static_cast<char*>(hc_) + o * HC_ELEMS * es;
     v.partial = partial_ + o * partial_per_crop_;
     v.gate = gate_ + o * 1152;
+    v.counter = se_counter_ + o;
     return v;
 }
 

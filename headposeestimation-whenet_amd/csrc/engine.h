@@ -111,6 +111,7 @@ class Engine {
     struct View {          // the activation arena as seen by a sub-batch starting at some crop
         void *x0, *x1, *e, *d, *hc;
         float *partial, *gate;
+        int* counter;
     };
     View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
@@ -128,6 +129,7 @@ class Engine {
     bool use_graph_ = true;
     int pw_impl_ = 0;
     int repeat_ = 1;
+    bool fuse_se_ = false;      // option "fuse_se": the front kernel's last workgroup per crop computes the SE gate
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
     bool tail_fused_ = false;   // option "tail": blocks 7..16 + head + heads as ONE launch, one workgroup per crop
                                 // (tail.hip). Correct and tested, but a lone CU needs ~1.1 ms per crop: it only matches
@@ -156,6 +158,7 @@ class Engine {
     size_t arena_bytes_ = 0;
     void *x0_ = nullptr, *x1_ = nullptr, *e_ = nullptr, *d_ = nullptr, *hc_ = nullptr;
     float *partial_ = nullptr, *gate_ = nullptr;
+    int* se_counter_ = nullptr;
     uint8_t* in_u8_ = nullptr;
     float* o_ypr_ = nullptr;
     int32_t* o_amax_ = nullptr;

@@ -24,6 +24,7 @@
 // the grouping of the squeeze-excite partial sums follows this kernel's own tiling.
 #include "device_math.h"
 #include "kernels.h"
+#include "se_device.h"
 
 namespace whenet {
 
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
                                                             const float* __restrict__ bd, T* __restrict__ out,
                                                             float* __restrict__ partial, int H, int Ho, int Cin,
                                                             int Cexp, int pad, int KSe, int NTe, int CC, int TH,
-                                                            int NSX, int tiles_x, int EH, int EW, int w_off) {
+                                                            int NSX, int tiles_x, int EH, int EW, int w_off,
+                                                            FrontSe se) {
     constexpr int V = Vec<T>::V;
     constexpr int SZ = int(sizeof(T));
     using VT = typename Vec<T>::type;
@@ -187,7 +189,46 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
     if (tid < ccur) {
         float t = 0.0f;
         for (int s = 0; s < NPC; ++s) t += s_red[s * ccur + tid];
-        partial[(size_t(b) * gridDim.x + tile) * Cexp + c0 + tid] = t;
+        float* dst = partial + (size_t(b) * gridDim.x + tile) * Cexp + c0 + tid;
+        // with the in-kernel hand-off the sums are stored write-through (sc1): visible device-wide
+        // once drained, no L2 write-back fence needed
+        if (se.counter != nullptr) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = t;
+    }
+    if (se.counter == nullptr) return;             // squeeze-excite runs as its own launch
+
+    // ---- the LAST workgroup of this crop to arrive finishes the block: squeeze-excite gate ------
+    // Hand-off across workgroups (other CUs / XCDs): the partial sums were stored write-through
+    // (sc1), every storing wave drains its stores, then one lane takes a ticket; the last arriver
+    // issues an agent-scope acquire (drops its L1) before any lane reads the other workgroups'
+    // partial sums.  No release fence (an L2 write-back per workgroup costs microseconds).  Nothing
+    // depends on dispatch order or placement.  The counter resets itself for the next launch.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* s_flag = reinterpret_cast<int*>(smem + w_off);        // depthwise taps are no longer needed
+    if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(se.counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = (ticket == int(gridDim.x * gridDim.y) - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*s_flag == 0) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(se.counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    float* s_mean = reinterpret_cast<float*>(smem);            // [1152]  (the tile region is free)
+    float* s_r = s_mean + 1152;                                // [64]
+    const float* pp = partial + size_t(b) * gridDim.x * Cexp;
+    float* gate_b = se.gate + size_t(b) * Cexp;
+    const float inv_hw = 1.0f / float(Ho * Ho);
+    switch ((se.R + 3) & ~3) {
+        case 4: se_gate_device<4, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
+        case 8: se_gate_device<8, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
+        case 12: se_gate_device<12, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
+        case 20: se_gate_device<20, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
+        case 28: se_gate_device<28, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
+        default: se_gate_device<48, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
     }
 }
 
@@ -206,7 +247,7 @@ void launch_t(const FrontArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((whenet_front_kernel<T, K, S>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
                        static_cast<T*>(a.out), a.partial, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
-                       p.tiles_x, p.EH, p.EW, p.w_off);
+                       p.tiles_x, p.EH, p.EW, p.w_off, a.se);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 

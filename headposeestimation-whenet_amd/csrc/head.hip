@@ -17,13 +17,15 @@ namespace {
 constexpr int HW = 49;
 
 template <typename T>
-__global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__ x, const float* __restrict__ feat_in,
+__global__ __launch_bounds__(1024) void whenet_heads_kernel(const T* __restrict__ x, const float* __restrict__ feat_in,
                                                            const float* __restrict__ logits_in,
                                                            const float* __restrict__ w, const float* __restrict__ bvec,
                                                            float* __restrict__ feat_out, float* __restrict__ logits_out,
                                                            float* __restrict__ ypr, int32_t* __restrict__ amax) {
     __shared__ float s_feat[FEAT];
-    __shared__ float s_part[4][N_LOGITS + 4];
+    constexpr int NTHR = 1024, NW = 16;            // a pure latency chain: spread thin
+    __shared__ float s_part[NW][N_LOGITS + 4];
+    __shared__ float s_gap[3][FEAT];
     __shared__ float s_logit[N_LOGITS + 4];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -31,36 +33,43 @@ __global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__
     if (logits_in == nullptr) {
         // ---- GAP: mean over the 49 positions (whenet.py:10); lane <-> 4 channels ------------
         if (x != nullptr) {
+            // lane <-> (4 channels, one third of the 49 positions): 16-17 independent loads in flight
             using V4 = T __attribute__((ext_vector_type(4)));
             const T* xb = x + size_t(b) * HW * FEAT;
-            for (int c4 = tid; c4 < FEAT / 4; c4 += 256) {
+            const int c4 = tid % (FEAT / 4), part = tid / (FEAT / 4);
+            if (part < 3) {
                 float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 7
-                for (int p = 0; p < HW; ++p) {
-                    const V4 v = *reinterpret_cast<const V4*>(xb + size_t(p) * FEAT + c4 * 4);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) t[i] += float(v[i]);
+                for (int i = 0; i < 17; ++i) {
+                    const int p = part + 3 * i;
+                    if (p < HW) {
+                        const V4 v = *reinterpret_cast<const V4*>(xb + size_t(p) * FEAT + c4 * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] += float(v[j]);
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s_feat[c4 * 4 + i] = t[i] * (1.0f / 49.0f);
+                for (int j = 0; j < 4; ++j) s_gap[part][c4 * 4 + j] = t[j];
             }
+            __syncthreads();
+            for (int c = tid; c < FEAT; c += NTHR) s_feat[c] = ((s_gap[0][c] + s_gap[1][c]) + s_gap[2][c]) * (1.0f / 49.0f);
         } else {
-            for (int c = tid; c < FEAT; c += 256) s_feat[c] = feat_in[size_t(b) * FEAT + c];
+            for (int c = tid; c < FEAT; c += NTHR) s_feat[c] = feat_in[size_t(b) * FEAT + c];
         }
         __syncthreads();
         if (feat_out != nullptr)
-            for (int c = tid; c < FEAT; c += 256) feat_out[size_t(b) * FEAT + c] = s_feat[c];
+            for (int c = tid; c < FEAT; c += NTHR) feat_out[size_t(b) * FEAT + c] = s_feat[c];
 
         // ---- Dense: logits[j] = sum_c feat[c]*W[c][j] + b[j]  (whenet.py:11-13) ------------
-        // 4 waves split the 1280-long contraction; lane l owns logits 4l..4l+3 (16-byte loads of
+        // 16 waves split the 1280-long contraction; lane l owns logits 4l..4l+3 (16-byte loads of
         // the [1280][252] kernel rows, 8 rows in flight).
         const int wave = tid >> 6, lane = tid & 63;
-        const int c_lo = wave * (FEAT / 4);
+        const int c_lo = wave * (FEAT / NW);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (lane < N_LOGITS / 4) {
             const float* wr = w + size_t(c_lo) * N_LOGITS + lane * 4;
 #pragma unroll 8
-            for (int c = 0; c < FEAT / 4; ++c) {
+            for (int c = 0; c < FEAT / NW; ++c) {
                 const float f = s_feat[c_lo + c];
                 const float4v wv = *reinterpret_cast<const float4v*>(wr + size_t(c) * N_LOGITS);
 #pragma unroll
@@ -70,7 +79,12 @@ __global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__
             for (int i = 0; i < 4; ++i) s_part[wave][lane * 4 + i] = acc[i];
         }
         __syncthreads();
-        if (tid < N_LOGITS) s_logit[tid] = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + bvec[tid];
+        if (tid < N_LOGITS) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) t += s_part[w2][tid];
+            s_logit[tid] = t + bvec[tid];
+        }
     } else {
         if (tid < N_LOGITS) s_logit[tid] = logits_in[size_t(b) * N_LOGITS + tid];
     }
@@ -124,11 +138,11 @@ __global__ __launch_bounds__(256) void whenet_heads_kernel(const T* __restrict__
 
 void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream) {
     if (dtype == WHENET_F16 && a.x != nullptr)
-        hipLaunchKernelGGL(whenet_heads_kernel<half_t>, dim3(a.n), dim3(256), 0, stream,
+        hipLaunchKernelGGL(whenet_heads_kernel<half_t>, dim3(a.n), dim3(1024), 0, stream,
                            static_cast<const half_t*>(a.x), a.feat_in, a.logits_in, a.w, a.b, a.feat, a.logits, a.ypr,
                            a.argmax);
     else
-        hipLaunchKernelGGL(whenet_heads_kernel<float>, dim3(a.n), dim3(256), 0, stream,
+        hipLaunchKernelGGL(whenet_heads_kernel<float>, dim3(a.n), dim3(1024), 0, stream,
                            static_cast<const float*>(a.x), a.feat_in, a.logits_in, a.w, a.b, a.feat, a.logits, a.ypr,
                            a.argmax);
     WHENET_HIP_CHECK(hipGetLastError());

@@ -107,6 +107,13 @@ struct FrontPlan {
     int ntiles() const { return tiles_x * tiles_y; }
 };
 FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp);
+// squeeze-excite finished inside the front kernel by the crop's last workgroup (counter != nullptr)
+struct FrontSe {
+    int* counter = nullptr;      // [n] arrival tickets, zero between launches (self-resetting)
+    const float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float* gate = nullptr;       // [n][Cexp]
+    int R = 0;
+};
 struct FrontArgs {
     const void* x;         // [n,H,H,Cin] T  block input
     const void* wep;       // packed expand weights (MFMA fragment order)
@@ -117,6 +124,7 @@ struct FrontArgs {
     float* partial;        // [n][ntiles][Cexp]
     int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
     FrontPlan plan;
+    FrontSe se;
 };
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 const char* kernel_name_front(int dtype, int k, int s);
