@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 fp32 latency leg")
     ap.add_argument("--repeat", type=int, default=1, help="debug: issue every kernel launch this many times")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent sub-batch chains per forward (0 = engine default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="engine option passed to whenet_set_option (e.g. fuse_project=7)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dump-layers", default="", help="write the per-launch profile (JSON) to this path")
     return ap.parse_args()
@@ -142,6 +144,9 @@ def main():
         h.set_option("repeat", args.repeat)
     if args.lanes > 0:
         h.set_option("lanes", args.lanes)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
 
     B = args.batch
     crops = synth.noise_crops(B, seed=rank)        # default_rng(seed) uint8

@@ -218,7 +218,7 @@ int whenet_front_plan(int dtype, int index, int32_t out[12]) {
         if (index < 2 || index > int(blocks.size())) return WHENET_EINVAL;
         const whenet::BlockSpec& b = blocks[size_t(index - 1)];
         const whenet::FrontPlan p = whenet::plan_front(dtype, b.k, b.s, b.h_in, b.h_out, b.cexp());
-        const int32_t v[12] = {256, p.CC, p.TH, p.NSX, p.tiles_x, p.tiles_y, p.chunks, p.EH, p.EW,
+        const int32_t v[12] = {p.threads, p.CC, p.TH, p.NSX, p.tiles_x, p.tiles_y, p.chunks, p.EH, p.EW,
                                int32_t(p.lds_bytes), p.w_off, b.cexp()};
         std::memcpy(out, v, sizeof(v));
         return WHENET_OK;

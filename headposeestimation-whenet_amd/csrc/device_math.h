@@ -21,6 +21,13 @@ __device__ __forceinline__ float swish_f(float x) {
     return x * sigmoid_f<PRECISE>(x);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
+// loads and stores (s_waitcnt vmcnt(0)), which would stall prefetched operands and output stores
+// at every phase boundary; the kernels that use this barrier exchange data through LDS only.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <typename T> struct IsF32 { static constexpr bool value = false; };
 template <> struct IsF32<float> { static constexpr bool value = true; };
 

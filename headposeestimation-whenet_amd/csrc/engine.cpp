@@ -185,6 +185,11 @@ void Engine::set_option(const std::string& key, long value) {
         fuse_se_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "fuse_project") {
+        WHENET_REQUIRE(value >= 0 && value <= 17, WHENET_EINVAL, "fuse_project must be 0 (off) or a first block index 1..17");
+        fuse_project_from_ = int(value);
+        sync();
+        drop_graphs();
     } else if (key == "fuse_front") {
         fuse_front_ = value != 0;
         sync();
@@ -222,7 +227,21 @@ void Engine::get_info(whenet_info_t* out) const {
     out->params_backbone = params_backbone_;
     out->params_heads = params_heads_;
     out->n_tensors = n_tensors_;
-    out->n_kernels_per_forward = tail_fused_ ? (fuse_front_ ? 20 : 25) : (fuse_front_ ? (fuse_se_ ? 36 : 51) : 66);
+    {
+        // stem + per block {expand, dw | front} {se} project + head conv + heads
+        int k = 1 + 2;
+        for (const DevBlock& b : blocks_) {
+            const int idx = b.spec.index;
+            if (tail_fused_ && idx >= 7) continue;
+            const bool has_expand = b.spec.expand != 1;
+            const bool front = fuse_front_ && has_expand;
+            k += front ? 1 : (has_expand ? 2 : 1);
+            const bool proj = fuse_project_from_ > 0 && idx >= fuse_project_from_ && pw_impl_ == 0 && !(front && fuse_se_);
+            k += (proj || (front && fuse_se_)) ? 1 : 2;
+        }
+        if (tail_fused_) k = k - 2 + 1;
+        out->n_kernels_per_forward = k;
+    }
     out->macs_per_crop = 384857312;
     out->arena_bytes = int64_t(arena_bytes_);
     out->capacity = cap_;
@@ -351,6 +370,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.NTe = b.expand.NTILES;
         a.n = n;
         a.plan = b.fplan;
+        a.plan.threads = front_threads(b.fplan, n);
         se_ntiles = b.fplan.ntiles();
         if (fuse_se_) {
             a.se.counter = v.counter;
@@ -361,7 +381,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
             a.se.gate = v.gate;
             a.se.R = b.se.R;
         }
-        R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
+        R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s, a.plan.threads).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
           [&] { launch_front(a, dtype_, s); });
     } else if (sp.has_expand()) {
@@ -399,6 +419,36 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.plan = b.dw.plan;
         R(p + "/dw", "dw", kernel_name_dw(dtype_, sp.k, sp.s), double(n) * (hw_in + hw_out) * cexp * es,
           2.0 * n * hw_out * sp.k * sp.k * cexp, [&] { launch_dw(a, dtype_, s); });
+    }
+    const bool proj_fused = fuse_project_from_ > 0 && sp.index >= fuse_project_from_ && pw_impl_ == 0 &&
+                            !(fused && fuse_se_);
+    if (proj_fused) {
+        ProjectArgs a{};
+        a.d = v.d;
+        a.wp = b.project.wp;
+        a.bias = b.project.bias;
+        a.partial = v.partial;
+        a.ntiles = se_ntiles;
+        a.inv_hw = 1.0f / float(hw_out);
+        a.w1t = b.se.w1t;
+        a.b1 = b.se.b1;
+        a.w2 = b.se.w2;
+        a.b2 = b.se.b2;
+        a.gate = v.gate;
+        a.res = sp.has_skip() ? in : nullptr;
+        a.out = out;
+        a.n = n;
+        a.HW = hw_out;
+        a.K = b.project.K;
+        a.N = b.project.N;
+        a.KS = b.project.KS;
+        a.NTILES = b.project.NTILES;
+        a.R = b.se.R;
+        R(p + "/project", "proj", kernel_name_project(a, dtype_).c_str(),
+          double(n) * hw_out * (a.K + a.N + (sp.has_skip() ? a.N : 0)) * es + double(n) * (a.ntiles + 1) * a.K * 4.0 +
+              2.0 * a.K * a.R * 4.0,
+          2.0 * n * hw_out * a.K * a.N + 4.0 * n * a.K * a.R, [&] { launch_project(a, dtype_, s); });
+        return;
     }
     if (!(fused && fuse_se_)) {
         SeArgs a{};

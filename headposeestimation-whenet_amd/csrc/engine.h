@@ -130,6 +130,8 @@ class Engine {
     int pw_impl_ = 0;
     int repeat_ = 1;
     bool fuse_se_ = false;      // option "fuse_se": the front kernel's last workgroup per crop computes the SE gate
+    int fuse_project_from_ = 0; // option "fuse_project": blocks >= this index run SE + project as ONE launch
+                                // (project.hip; 0 = never).  Bitwise equal to the two launches; measured no faster.
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
     bool tail_fused_ = false;   // option "tail": blocks 7..16 + head + heads as ONE launch, one workgroup per crop
                                 // (tail.hip). Correct and tested, but a lone CU needs ~1.1 ms per crop: it only matches

@@ -25,6 +25,10 @@
 #include "device_math.h"
 #include "kernels.h"
 #include "se_device.h"
+#include "stamps.h"
+
+#include <cstdlib>
+#include <string>
 
 namespace whenet {
 
@@ -32,11 +36,9 @@ namespace {
 
 constexpr int P = 7;
 constexpr int VC = 4;
-constexpr int NTHR = 256;
-constexpr int NWAVE = 4;
 
-template <typename T, int K, int S>
-__global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict__ x, const T* __restrict__ wep,
+template <typename T, int K, int S, int NTHR>
+__global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restrict__ x, const T* __restrict__ wep,
                                                             const float* __restrict__ be,
                                                             const float* __restrict__ wd,
                                                             const float* __restrict__ bd, T* __restrict__ out,
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
     using OT = T __attribute__((ext_vector_type(4)));
     using VCT = OT;
     constexpr int NIX = (P - 1) * S + K;
+    constexpr int NWAVE = NTHR / 64;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* E = smem;                                            // [EH*EW] pixels, pitch EP
@@ -68,63 +71,118 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
     const int oy0 = tyi * TH, ox0 = txi * NSX * P;
     const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
 
-    for (int i = tid; i < EH * EW * EP / 16; i += NTHR) reinterpret_cast<VT*>(E)[i] = vec_zero<T>();
-    for (int i = tid; i < K * K * ccur; i += NTHR) {
-        const int tap = i / ccur, c = i - tap * ccur;
-        s_w[tap * CC + c] = wd[size_t(tap) * Cexp + c0 + c];
-    }
-    __syncthreads();
-
+    STAMP(0);
     // ---- expand (MFMA) over the in-image pixels of the input tile -> E ------------------------
-    {
-        const int iy_lo = iy0 < 0 ? 0 : iy0, ix_lo = ix0 < 0 ? 0 : ix0;
-        const int iy_hi = (iy0 + EH < H) ? iy0 + EH : H, ix_hi = (ix0 + EW < H) ? ix0 + EW : H;
-        const int RW = ix_hi - ix_lo, npx = (iy_hi - iy_lo) * RW;
-        const int nstrip = (npx + 31) >> 5, ntile = (ccur + 31) >> 5;
-        for (int t = wave; t < nstrip * ntile; t += NWAVE) {
-            const int tl = t / nstrip, strip = t - tl * nstrip;
-            const int q = strip * 32 + lm;
-            const bool valid = q < npx;
-            const int ry = valid ? q / RW : 0, rx = valid ? q - ry * RW : 0;
-            const int iy = iy_lo + ry, ix = ix_lo + rx;
-            const T* xrow = x + ((size_t(b) * H + iy) * H + ix) * Cin + g * V;
-            float16v acc;
+    // A task = one 32-pixel strip x one 32-channel tile; a wave walks its tasks with the operands
+    // of the NEXT task (first 4 k-steps + bias) already in flight while it applies BN+Swish to the
+    // current one: the only exposed global-memory round trip is the first.
+    const int iy_lo = iy0 < 0 ? 0 : iy0, ix_lo = ix0 < 0 ? 0 : ix0;
+    const int iy_hi = (iy0 + EH < H) ? iy0 + EH : H, ix_hi = (ix0 + EW < H) ? ix0 + EW : H;
+    const int RW = ix_hi - ix_lo, npx = (iy_hi - iy_lo) * RW;
+    const int nstrip = (npx + 31) >> 5, ntile = (ccur + 31) >> 5;
+    const int ntask = nstrip * ntile;
+
+    struct Task {
+        bool valid;
+        int tl, eoff;
+        const T* xrow;
+        const VT* wf;
+    };
+    auto make_task = [&](int t) -> Task {
+        Task k;
+        k.tl = t / nstrip;
+        const int strip = t - k.tl * nstrip;
+        const int q = strip * 32 + lm;
+        k.valid = t < ntask && q < npx;
+        const int ry = k.valid ? q / RW : 0, rx = k.valid ? q - ry * RW : 0;
+        const int iy = iy_lo + ry, ix = ix_lo + rx;
+        k.xrow = x + ((size_t(b) * H + iy) * H + ix) * Cin + g * V;
+        k.eoff = ((iy - iy0) * EW + (ix - ix0)) * EP;
+        k.wf = reinterpret_cast<const VT*>(wep) + size_t((c0 >> 5) + k.tl) * 64 + lane;
+        return k;
+    };
+    auto load_ops = [&](const Task& k, int ks, VT (&w)[4], VT (&a)[4]) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const VT* wf = reinterpret_cast<const VT*>(wep) + size_t((c0 >> 5) + tl) * 64 + lane;
-            for (int ks = 0; ks < KSe; ks += 4) {
-                VT w[4], a[4];
+        for (int u = 0; u < 4; ++u) w[u] = (ks + u < KSe) ? k.wf[size_t(ks + u) * NTe * 64] : vec_zero<T>();
 #pragma unroll
-                for (int u = 0; u < 4; ++u) w[u] = (ks + u < KSe) ? wf[size_t(ks + u) * NTe * 64] : vec_zero<T>();
+        for (int u = 0; u < 4; ++u)
+            a[u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
+                       ? *reinterpret_cast<const VT*>(k.xrow + size_t(ks + u) * 2 * V)
+                       : vec_zero<T>();
+    };
+    auto load_bias = [&](const Task& k, float4v (&bv)[4]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    a[u] = (valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
-                               ? *reinterpret_cast<const VT*>(xrow + size_t(ks + u) * 2 * V)
-                               : vec_zero<T>();
+        for (int qq = 0; qq < 4; ++qq) {
+            const int nl = k.tl * 32 + 8 * qq + 4 * g;
+            bv[qq] = (nl < ccur) ? *reinterpret_cast<const float4v*>(be + c0 + nl) : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // Loads are issued oldest-needed first (the vector-memory counter retires in order): the chunk's
+    // depthwise taps, then the first task's operands; the taps are parked in LDS and E is zeroed (the
+    // halo outside the image is TF 'SAME' padding of the EXPANDED tensor) while the operands are
+    // still in flight -- the barrier below orders LDS traffic only.
+    constexpr int WR = (K * K * 160 + NTHR - 1) / NTHR;
+    float wreg[WR];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) Mfma<T>::step(w[u], a[u], acc);
-            }
-            if (valid) {
-                unsigned char* epix = E + size_t((iy - iy0) * EW + (ix - ix0)) * EP;
+    for (int j = 0; j < WR; ++j) {
+        const int i = tid + j * NTHR;
+        const int tap = i / ccur, c = i - tap * ccur;
+        wreg[j] = (i < K * K * ccur) ? wd[size_t(tap) * Cexp + c0 + c] : 0.f;
+    }
+    Task cur = make_task(wave);
+    VT w[4], a[4];
+    float4v bv[4];
+    if (wave < ntask) {
+        load_bias(cur, bv);
+        load_ops(cur, 0, w, a);
+    }
+    for (int i = tid; i < EH * EW * EP / 16; i += NTHR) reinterpret_cast<VT*>(E)[i] = vec_zero<T>();
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int nl = tl * 32 + 8 * qq + 4 * g;
-                    if (nl < ccur) {
-                        const float4v bv = *reinterpret_cast<const float4v*>(be + c0 + nl);
-                        OT o;
+    for (int j = 0; j < WR; ++j) {
+        const int i = tid + j * NTHR;
+        const int tap = i / ccur, c = i - tap * ccur;
+        if (i < K * K * ccur) s_w[tap * CC + c] = wreg[j];
+    }
+    lds_barrier();
+    STAMP(1);
+
+    for (int t = wave; t < ntask; t += NWAVE) {
+        float16v acc;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = T(swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[r]));
-                        *reinterpret_cast<OT*>(epix + nl * SZ) = o;
-                    }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Mfma<T>::step(w[u], a[u], acc);
+        for (int ks = 4; ks < KSe; ks += 4) {
+            load_ops(cur, ks, w, a);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Mfma<T>::step(w[u], a[u], acc);
+        }
+        const Task nxt = make_task(t + NWAVE);
+        if (t + NWAVE < ntask) load_ops(nxt, 0, w, a);
+        if (cur.valid) {
+            unsigned char* epix = E + cur.eoff;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int nl = cur.tl * 32 + 8 * qq + 4 * g;
+                if (nl < ccur) {
+                    OT o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = T(swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[qq][r]));
+                    *reinterpret_cast<OT*>(epix + nl * SZ) = o;
                 }
             }
         }
+        if (t + NWAVE < ntask && nxt.tl != cur.tl) load_bias(nxt, bv);     // (wave-uniform, rare)
+        cur = nxt;
     }
-    __syncthreads();
+    STAMP(2);
+    lds_barrier();
+    STAMP(3);
 
     // ---- depthwise taps out of E: lane = (4-channel group cg, strip sidx) ---------------------
     const int CG = ccur / VC;
-    const int NPC = NTHR / CG;
+    const int NPC = (NTHR / CG < TH * NSX) ? NTHR / CG : TH * NSX;    // tap slots (strips) in use
     const int cg = tid % CG;
     const int sidx = tid / CG;
     const int ty = sidx / NSX, sx = sidx - ty * NSX;
@@ -137,7 +195,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
 #pragma unroll
         for (int v = 0; v < VC; ++v) acc[p][v] = 0.0f;
     if (active) {
-#pragma unroll
+#pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
             float wr[K][VC];
 #pragma unroll
@@ -164,6 +222,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
             }
         }
     }
+    STAMP(4);
     float sum[VC] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         const float4v bs = *reinterpret_cast<const float4v*>(bd + c0 + cg * VC);
@@ -180,12 +239,13 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
             *reinterpret_cast<VCT*>(dst + size_t(p) * Cexp) = o;
         }
     }
-    __syncthreads();                                   // every lane is done reading E
+    STAMP(5);
+    lds_barrier();                                     // every lane is done reading E (stores stay in flight)
     if (lane_ok) {
 #pragma unroll
         for (int v = 0; v < VC; ++v) s_red[sidx * ccur + cg * VC + v] = sum[v];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < ccur) {
         float t = 0.0f;
         for (int s = 0; s < NPC; ++s) t += s_red[s * ccur + tid];
@@ -195,6 +255,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
         if (se.counter != nullptr) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *dst = t;
     }
+    STAMP(6);
     if (se.counter == nullptr) return;             // squeeze-excite runs as its own launch
 
     // ---- the LAST workgroup of this crop to arrive finishes the block: squeeze-excite gate ------
@@ -232,7 +293,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, int NTHR>
 void launch_t(const FrontArgs& a, hipStream_t stream) {
     const FrontPlan& p = a.plan;
     dim3 grid(p.tiles_x * p.tiles_y, p.chunks, a.n);
@@ -240,24 +301,34 @@ void launch_t(const FrontArgs& a, hipStream_t stream) {
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
     if (p.lds_bytes > 64 * 1024 && dev >= 0 && dev < 64 && !attr[dev]) {
-        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S>),
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S, NTHR>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr[dev] = true;
     }
-    hipLaunchKernelGGL((whenet_front_kernel<T, K, S>), grid, dim3(NTHR), p.lds_bytes, stream,
+    hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
                        static_cast<T*>(a.out), a.partial, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
                        p.tiles_x, p.EH, p.EW, p.w_off, a.se);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
-template <typename T>
+template <typename T, int NTHR>
 void launch_ks(const FrontArgs& a, hipStream_t stream) {
-    if (a.k == 3 && a.s == 1) launch_t<T, 3, 1>(a, stream);
-    else if (a.k == 3 && a.s == 2) launch_t<T, 3, 2>(a, stream);
-    else if (a.k == 5 && a.s == 1) launch_t<T, 5, 1>(a, stream);
-    else if (a.k == 5 && a.s == 2) launch_t<T, 5, 2>(a, stream);
+    if (a.k == 3 && a.s == 1) launch_t<T, 3, 1, NTHR>(a, stream);
+    else if (a.k == 3 && a.s == 2) launch_t<T, 3, 2, NTHR>(a, stream);
+    else if (a.k == 5 && a.s == 1) launch_t<T, 5, 1, NTHR>(a, stream);
+    else if (a.k == 5 && a.s == 2) launch_t<T, 5, 2, NTHR>(a, stream);
     else throw Error(WHENET_EINVAL, "front: unsupported kernel/stride");
+}
+
+template <typename T>
+void launch_thr(const FrontArgs& a, hipStream_t stream) {
+    switch (a.plan.threads) {
+        case 256: launch_ks<T, 256>(a, stream); break;
+        case 512: launch_ks<T, 512>(a, stream); break;
+        case 1024: launch_ks<T, 1024>(a, stream); break;
+        default: throw Error(WHENET_EINVAL, "front: threads must be 256, 512 or 1024");
+    }
 }
 
 }  // namespace
@@ -266,6 +337,7 @@ void launch_ks(const FrontArgs& a, hipStream_t stream) {
 // layer), TH output rows, NSX 7-pixel strips; 256 lanes; LDS <= 64 KiB.  Score = useful lanes x
 // halo efficiency (also the expand recompute factor) x occupancy.
 FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
+    constexpr int NTHR = 256;           // tap lanes the tile is planned for (the kernel may run more lanes)
     const int SZ = (dtype == WHENET_F16) ? 2 : 4;
     WHENET_REQUIRE(Cexp % VC == 0 && Ho % P == 0, WHENET_EINVAL, "front: unsupported geometry");
     const int spr = Ho / P;
@@ -275,6 +347,7 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
         int cc = CC;
         if (cc > Cexp) cc = Cexp;
         if (cc != Cexp && cc % 32) continue;
+        if (k == 5 && cc > 128) continue;          // the kernel keeps the chunk's taps in <= 13 registers per lane
         const int CG = cc / VC;
         if (CG > NTHR) continue;
         const int NS = NTHR / CG;
@@ -323,21 +396,27 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
     }
     WHENET_REQUIRE(best_score > 0, WHENET_EINVAL, "front: no tile plan fits");
     (void)H;
+    best.threads = 256;
     return best;
 }
 
-void launch_front(const FrontArgs& a, int dtype, hipStream_t stream) {
-    if (dtype == WHENET_F16) launch_ks<half_t>(a, stream);
-    else launch_ks<float>(a, stream);
+// Lanes per workgroup for a launch of n crops.  The tile (and every result bit) is the same either
+// way: extra waves only share the expand tasks.  When the whole launch fits on the chip at once
+// (<= 2 workgroups per CU) the kernel is one workgroup's critical path, so 8 waves shorten it;
+// beyond that 4-wave workgroups pack the CUs better.
+int front_threads(const FrontPlan& p, int n) {
+    if (const char* e = getenv("WHENET_FRONT_THREADS")) return atoi(e);       // probes only
+    return (long(n) * p.ntiles() * p.chunks <= 512) ? 512 : 256;
 }
 
-const char* kernel_name_front(int dtype, int k, int s) {
-    static const char* names[2][2][2] = {
-        {{"whenet_front_kernel<float, 3, 1>", "whenet_front_kernel<float, 3, 2>"},
-         {"whenet_front_kernel<float, 5, 1>", "whenet_front_kernel<float, 5, 2>"}},
-        {{"whenet_front_kernel<_Float16, 3, 1>", "whenet_front_kernel<_Float16, 3, 2>"},
-         {"whenet_front_kernel<_Float16, 5, 1>", "whenet_front_kernel<_Float16, 5, 2>"}}};
-    return names[dtype == WHENET_F16][k == 5][s == 2];
+void launch_front(const FrontArgs& a, int dtype, hipStream_t stream) {
+    if (dtype == WHENET_F16) launch_thr<half_t>(a, stream);
+    else launch_thr<float>(a, stream);
+}
+
+std::string kernel_name_front(int dtype, int k, int s, int threads) {
+    return std::string("whenet_front_kernel<") + (dtype == WHENET_F16 ? "_Float16" : "float") + ", " +
+           std::to_string(k) + ", " + std::to_string(s) + ", " + std::to_string(threads) + ">";
 }
 
 }  // namespace whenet

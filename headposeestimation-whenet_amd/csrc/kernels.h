@@ -78,6 +78,25 @@ struct PwArgs {
 };
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream);
 
+// ---- project.hip ------------------------------------------------------------------------
+// SE gate + gated project conv + BN (+ skip) as one launch: every workgroup recomputes its crop's
+// gate from the tile partial sums (bitwise the arithmetic of launch_se + launch_pw).
+struct ProjectArgs {
+    const void* d;         // [n][HW][K] T   depthwise output
+    const void* wp;        // packed MFMA operand image of the project conv
+    const float* bias;     // [N]
+    const float* partial;  // [n][ntiles][K] tile partial sums of d
+    int ntiles;
+    float inv_hw;
+    const float *w1t, *b1, *w2, *b2;   // SE kernels as in SeArgs
+    float* gate;           // [n][K] (written by the first workgroup of each crop) or nullptr
+    const void* res;       // [n][HW][N] T or nullptr
+    void* out;             // [n][HW][N] T
+    int n, HW, K, N, KS, NTILES, R;
+};
+void launch_project(const ProjectArgs& a, int dtype, hipStream_t stream);
+std::string kernel_name_project(const ProjectArgs& a, int dtype);
+
 // ---- head.hip ---------------------------------------------------------------------------
 // GlobalAveragePooling2D + Dense(120|66|66) + softmax-expectation decode + argmax
 // (whenet.py:10-13, 28-33; utils.py:7-11).
@@ -98,6 +117,8 @@ void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream);
 // ---- front.hip --------------------------------------------------------------------------
 // expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).
 struct FrontPlan {
+    int threads = 256;     // lanes per workgroup (the tile is planned for 256 tap lanes; the extra
+                           // waves only share the expand tasks)
     int CC = 32;           // expanded channels per workgroup
     int TH = 1, NSX = 1;   // output tile: TH rows x 7*NSX columns
     int tiles_x = 1, tiles_y = 1, chunks = 1;
@@ -107,6 +128,7 @@ struct FrontPlan {
     int ntiles() const { return tiles_x * tiles_y; }
 };
 FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp);
+int front_threads(const FrontPlan& p, int n);    // lanes per workgroup for a launch of n crops (256 | 512)
 // squeeze-excite finished inside the front kernel by the crop's last workgroup (counter != nullptr)
 struct FrontSe {
     int* counter = nullptr;      // [n] arrival tickets, zero between launches (self-resetting)
@@ -127,7 +149,7 @@ struct FrontArgs {
     FrontSe se;
 };
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
-const char* kernel_name_front(int dtype, int k, int s);
+std::string kernel_name_front(int dtype, int k, int s, int threads);
 
 // ---- tail.hip ---------------------------------------------------------------------------
 // Blocks 7..16 + head conv + GAP + Dense + decode as ONE launch, one workgroup per crop.

@@ -67,7 +67,7 @@ def test_info(handle):
     i = handle.info()
     assert i.abi_version == _lib.ABI_VERSION
     assert (i.params_backbone, i.params_heads, i.n_tensors) == (4_049_564, 322_812, 315)
-    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward in (20, 25, 36, 51, 66)
+    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 51   # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
 
@@ -96,6 +96,15 @@ def test_mbconv_block_kernels(handle, taps, index):
         assert rel_err(r0["dw"], taps[f"{p}/dw"]) < 2 * t, "dw (unfused)"
         assert rel_err(r0["out"], taps[f"{p}/out"]) < 3 * t, "out (unfused)"
     r = handle.op_block(index, x.astype(np.float32))
+    # option fuse_project: SE gate + project GEMM as ONE launch (project.hip) must give the same
+    # gate and block output bitwise as the default two launches (se.hip + pw.hip)
+    handle.set_option("fuse_project", 1)
+    try:
+        r2 = handle.op_block(index, x.astype(np.float32))
+    finally:
+        handle.set_option("fuse_project", 0)
+    assert np.array_equal(r["gate"], r2["gate"]), "gate: fused SE+project differs from se.hip"
+    assert np.array_equal(r["out"], r2["out"]), "out: fused SE+project differs from se.hip + pw.hip"
     if b.has_expand:
         assert np.array_equal(r["dw"], r0["dw"]), "fused expand+depthwise differs from pw+dw"
         # option fuse_se: squeeze-excite finished by the front kernel's last workgroup per crop
