@@ -165,12 +165,12 @@ __global__ __launch_bounds__(256) void whenet_dw_kernel(const T* __restrict__ in
             *reinterpret_cast<VCT*>(dst + size_t(p) * C) = o;
         }
     }
-    __syncthreads();                               // everyone is done reading s_tile
+    lds_barrier();                               // everyone is done reading s_tile
     if (lane_ok) {
 #pragma unroll
         for (int v = 0; v < VC; ++v) s_red[sidx * CC + cg * VC + v] = sum[v];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < CC) {
         float t = 0.0f;
         for (int s = 0; s < NPC; ++s) t += s_red[s * CC + tid];

@@ -115,6 +115,7 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
         b.se.w1t = upload(hb.se.w1t);
         b.se.b1 = upload(hb.se.b1);
         b.se.w2 = upload(hb.se.w2);
+        b.se.w2c = upload(hb.se.w2c);
         b.se.b2 = upload(hb.se.b2);
         b.project = upload_pw(hb.project);
         partial_per_crop_ = std::max(partial_per_crop_, size_t(b.dw.plan.ntiles()) * b.dw.C);
@@ -457,7 +458,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.inv_hw = 1.0f / float(hw_out);
         a.w1t = b.se.w1t;
         a.b1 = b.se.b1;
-        a.w2 = b.se.w2;
+        a.w2c = b.se.w2c;
         a.b2 = b.se.b2;
         a.gate = v.gate;
         a.C = b.se.C;

@@ -30,6 +30,7 @@ struct DevDw {
 struct DevSe {
     int C = 0, R = 0;
     float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float* w2c = nullptr;      // [C][RP] (se.hip reads a channel's whole excite row with 16-byte loads)
 };
 struct DevBlock {
     BlockSpec spec;

@@ -54,7 +54,7 @@ struct SeArgs {
     float inv_hw;
     const float* w1t;      // [R][C]  se_reduce kernel, transposed
     const float* b1;       // [R]
-    const float* w2;       // [R][C]
+    const float* w2c;      // [C][RP]  se_expand kernel, channel-major, R zero-padded to RP
     const float* b2;       // [C]
     float* gate;           // [n][C]
     int C, R, n;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s_red[((wave - 1) * NT * 16 + t * 16 + r) * 64 + lane] = acc[t][r];
         }
-        __syncthreads();
+        lds_barrier();
         if (wave > 0) return;
 #pragma unroll
         for (int w = 0; w < SK - 1; ++w)
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                 *reinterpret_cast<VT*>(out + size_t(rowg) * N + n) = float_to_vec<T>(y);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

@@ -6,15 +6,20 @@
 // fused into the project GEMM's operand load, pw.hip).  `reduced` = int(0.25 * block INPUT
 // filters).  All f32, fixed summation order -> bitwise reproducible.
 //
-// 2*C*R MACs per crop (0.2 % of the network): the kernel is pure latency, so every phase is
-// laid out for memory-level parallelism instead of arithmetic:
-//   squeeze  lane <-> channel, tile partials summed with 4 independent loads in flight;
-//   reduce   lane <-> channel slice, all R outputs accumulated at once in registers from
-//            16-byte loads of the [C][RP] weight rows (RP = R padded to a multiple of 4),
-//            then one shuffle tree per output and a 4-wave combine through LDS;
-//   excite   lane <-> channel, W2 rows are coalesced across lanes, 4 loads in flight.
+// 2*C*R MACs per crop (0.2 % of the network): the kernel is pure latency, so it is laid out as
+// ONE dependent memory round trip where the shapes allow it:
+//   * every weight load is independent of the data, so the fc1 rows (and, when they fit the
+//     register budget, the lane's fc2 row) are issued BEFORE the tile partial sums; the barriers
+//     order LDS traffic only (lds_barrier), so those loads stay in flight across them;
+//   * squeeze: the 8 running sums of a channel (tiles i = u mod 8) are spread over 8 lanes when
+//     8*C <= 1024 (blocks 1-2, 56-64 tiles) so that all tile loads are in flight at once, and
+//     combined through LDS in the same fixed order; otherwise a lane issues 16 tiles per trip;
+//   * excite: the se_expand kernel is stored channel-major [C][RP]: a lane's whole row is RP/4
+//     16-byte loads from one 64..192-byte segment (the [R][C] form touched RP pages per wave).
+// The arithmetic and its summation order are those of se_device.h / project.hip.
 #include "device_math.h"
 #include "kernels.h"
+#include "stamps.h"
 
 namespace whenet {
 
@@ -23,86 +28,140 @@ namespace {
 template <int RP>
 __global__ __launch_bounds__(1024) void whenet_se_kernel(const float* __restrict__ partial, int ntiles, float inv_hw,
                                                         const float* __restrict__ w1t, const float* __restrict__ b1,
-                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const float* __restrict__ w2c, const float* __restrict__ b2,
                                                         float* __restrict__ gate, int C, int R) {
+    constexpr int NW = 16, NTHR = NW * 64;
+    constexpr int JPW = (RP + NW - 1) / NW;          // fc1 outputs per wave (<= 3)
+    constexpr int CPL = 1152 / 64;                    // channel slots per lane (18)
+    constexpr int NCI = (RP == 48) ? 2 : 1;           // channels per lane in excite (C <= 1024 unless RP = 48)
+    constexpr bool PRE2 = RP <= 28;                   // fc2 row prefetched before the fc1 arithmetic
     __shared__ float s_mean[1152];
-    constexpr int NW = 16;                      // 1024 lanes: the kernel is a pure latency chain,
-    constexpr int NTHR = NW * 64;               // so it is spread as thin as a workgroup allows
     __shared__ float s_r[RP];
+    __shared__ float s_t[8][128];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
-    // squeeze: mean over the map = (sum of the depthwise kernel's tile partials) / (H*W);
-    // 8 independent loads in flight per lane
+    STAMP(0);
+    // fc1 rows: wave w owns outputs j = w, w+16, ..; its lanes stride over c (coalesced)
+    float wv1[JPW][CPL];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const int j = wave + NW * jj;
+        const float* wrow = w1t + size_t(j < R ? j : 0) * C;
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) {
+            const int c = lane + 64 * u;
+            wv1[jj][u] = (j < R && c < C) ? wrow[c] : 0.f;
+        }
+    }
+
+    // squeeze: mean over the map = (sum of the producing kernel's tile partials) / (H*W), as 8
+    // running sums t[u] over tiles i = u mod 8, combined ((t0+t1)+(t2+t3))+((t4+t5)+(t6+t7))
     const float* pp = partial + size_t(b) * ntiles * C;
-    for (int c = tid; c < C; c += NTHR) {
-        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < ntiles; i += 8) {
+    const bool wide = 8 * C <= NTHR && ntiles <= 64;          // (uniform)
+    if (wide) {
+        const int u = tid / C, c = tid - u * C;
+        if (u < 8) {
+            float x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i + u < ntiles) t[u] += pp[size_t(i + u) * C + c];
+            for (int k = 0; k < 8; ++k) x[k] = (u + 8 * k < ntiles) ? pp[size_t(u + 8 * k) * C + c] : 0.f;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (u + 8 * k < ntiles) t += x[k];
+            s_t[u][c] = t;
         }
-        s_mean[c] = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * inv_hw;
+    } else {
+        for (int c = tid; c < C; c += NTHR) {
+            float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < ntiles; i += 16) {
+                float x0[8], x1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    x0[u] = (i + u < ntiles) ? pp[size_t(i + u) * C + c] : 0.f;
+                    x1[u] = (i + 8 + u < ntiles) ? pp[size_t(i + 8 + u) * C + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (i + u < ntiles) t[u] += x0[u];
+                    if (i + 8 + u < ntiles) t[u] += x1[u];
+                }
+            }
+            s_mean[c] = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * inv_hw;
+        }
     }
-    __syncthreads();
 
-    // reduce: r[j] = swish(b1[j] + sum_c mean[c] * W1[c][j]).  Wave w owns outputs j = w, w+16, ..;
-    // its lanes stride over c (coalesced 256-byte rows of the transposed kernel), all loads of
-    // an output are independent, one 6-step shuffle tree per output.
-    constexpr int JPW = (RP + NW - 1) / NW;          // outputs per wave (<= 3)
-    constexpr int CPL = 1152 / 64;                    // channel slots per lane (18)
-    {
-        float wv[JPW][CPL];
+    STAMP(1);
+    // fc2 row(s) of this lane's channel(s)
+    float wv2[NCI][RP];
+    auto load_w2 = [&]() {
 #pragma unroll
-        for (int jj = 0; jj < JPW; ++jj) {
-            const int j = wave + NW * jj;
-            const float* wrow = w1t + size_t(j < R ? j : 0) * C;
+        for (int ci = 0; ci < NCI; ++ci) {
+            const int c = tid + ci * NTHR;
+            const float4v* wrow = reinterpret_cast<const float4v*>(w2c + size_t(c < C ? c : 0) * RP);
 #pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                const int c = lane + 64 * u;
-                wv[jj][u] = (j < R && c < C) ? wrow[c] : 0.f;          // all loads in flight at once
+            for (int j = 0; j < RP; j += 4) {
+                const float4v v = wrow[j >> 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv2[ci][j + q] = v[q];
             }
         }
-#pragma unroll
-        for (int jj = 0; jj < JPW; ++jj) {
-            const int j = wave + NW * jj;
-            float p[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < CPL; ++u) {
-                const int c = lane + 64 * u;
-                p[u & 3] = fmaf((c < C) ? s_mean[c] : 0.f, wv[jj][u], p[u & 3]);
-            }
-            float t = (p[0] + p[1]) + (p[2] + p[3]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-            if (lane == 0 && j < RP) s_r[j] = (j < R) ? swish_f<true>(t + b1[j]) : 0.f;
-        }
-    }
-    __syncthreads();
+    };
+    if constexpr (PRE2) load_w2();
 
-    // excite: gate[c] = sigmoid(b2[c] + sum_j r[j] * W2[j][c]); all R loads of a channel are
-    // issued before the first FMA (R <= RP is a compile-time bound -> fully unrolled)
-    for (int c = tid; c < C; c += NTHR) {
-        float wv[RP];
-#pragma unroll
-        for (int j = 0; j < RP; ++j) wv[j] = (j < R) ? w2[size_t(j) * C + c] : 0.f;
-        float t0 = b2[c], t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-        for (int j = 0; j < RP; j += 4) {
-            t0 = fmaf(s_r[j], wv[j], t0);
-            t1 = fmaf(s_r[j + 1], wv[j + 1], t1);
-            t2 = fmaf(s_r[j + 2], wv[j + 2], t2);
-            t3 = fmaf(s_r[j + 3], wv[j + 3], t3);
-        }
-        gate[size_t(b) * C + c] = sigmoid_f<true>((t0 + t1) + (t2 + t3));
+    if (wide) {
+        lds_barrier();
+        if (tid < C)
+            s_mean[tid] = (((s_t[0][tid] + s_t[1][tid]) + (s_t[2][tid] + s_t[3][tid])) +
+                           ((s_t[4][tid] + s_t[5][tid]) + (s_t[6][tid] + s_t[7][tid]))) * inv_hw;
     }
+    lds_barrier();
+    STAMP(2);
+
+    // reduce: r[j] = swish(b1[j] + sum_c mean[c] * W1[c][j]); one 6-step shuffle tree per output
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const int j = wave + NW * jj;
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < CPL; ++u) {
+            const int c = lane + 64 * u;
+            p[u & 3] = fmaf((c < C) ? s_mean[c] : 0.f, wv1[jj][u], p[u & 3]);
+        }
+        float t = (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0 && j < RP) s_r[j] = (j < R) ? swish_f<true>(t + b1[j]) : 0.f;
+    }
+    STAMP(3);
+    if constexpr (!PRE2) load_w2();
+    lds_barrier();
+    STAMP(4);
+
+    // excite: gate[c] = sigmoid(b2[c] + sum_j r[j] * W2[j][c])
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci) {
+        const int c = tid + ci * NTHR;
+        if (c < C) {
+            float t0 = b2[c], t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < RP; j += 4) {
+                t0 = fmaf(s_r[j], wv2[ci][j], t0);
+                t1 = fmaf(s_r[j + 1], wv2[ci][j + 1], t1);
+                t2 = fmaf(s_r[j + 2], wv2[ci][j + 2], t2);
+                t3 = fmaf(s_r[j + 3], wv2[ci][j + 3], t3);
+            }
+            gate[size_t(b) * C + c] = sigmoid_f<true>((t0 + t1) + (t2 + t3));
+        }
+    }
+    STAMP(5);
 }
 
 template <int RP>
 void launch_rp(const SeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(whenet_se_kernel<RP>, dim3(a.n), dim3(1024), 0, stream, a.partial, a.ntiles, a.inv_hw, a.w1t,
-                       a.b1, a.w2, a.b2, a.gate, a.C, a.R);
+                       a.b1, a.w2c, a.b2, a.gate, a.C, a.R);
 }
 
 }  // namespace

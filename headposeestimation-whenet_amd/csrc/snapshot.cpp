@@ -202,6 +202,10 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
                 for (uint32_t j = 0; j < r; ++j) hb.se.w1t[size_t(j) * cexp + c] = w1[size_t(c) * r + j];
             hb.se.b1.assign(b1, b1 + r);
             hb.se.w2.assign(w2, w2 + size_t(r) * cexp);
+            const uint32_t rp = (r + 3u) & ~3u;
+            hb.se.w2c.assign(size_t(cexp) * rp, 0.0f);
+            for (uint32_t j = 0; j < r; ++j)
+                for (uint32_t c = 0; c < cexp; ++c) hb.se.w2c[size_t(c) * rp + j] = w2[size_t(j) * cexp + c];
             hb.se.b2.assign(b2, b2 + cexp);
         }
         hb.project = make_pw(t, p + "/project", p + "/project_bn", cexp, cout, dtype);

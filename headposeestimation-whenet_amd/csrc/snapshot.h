@@ -46,6 +46,7 @@ struct HostSe {
     std::vector<float> w1t;          // [R][C]  (se_reduce kernel transposed)
     std::vector<float> b1;           // [R]
     std::vector<float> w2;           // [R][C]  (se_expand kernel)
+    std::vector<float> w2c;          // [C][RP] the same kernel channel-major, R zero-padded to a multiple of 4
     std::vector<float> b2;           // [C]
 };
 

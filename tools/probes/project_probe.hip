@@ -26,7 +26,7 @@ template <typename T> T* dalloc(size_t n, float scale) {
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 16;
     const Shape shapes[] = {
-        {"b1", 112 * 112, 32, 16, 8, 0, 56}, {"b3", 56 * 56, 144, 24, 6, 1, 14}, {"b4", 28 * 28, 144, 40, 6, 0, 8},
+        {"b1", 112 * 112, 32, 16, 8, 0, 56}, {"b2", 56 * 56, 96, 24, 4, 0, 64}, {"b3", 56 * 56, 144, 24, 6, 1, 14}, {"b4", 28 * 28, 144, 40, 6, 0, 8},
         {"b6", 14 * 14, 240, 80, 10, 0, 2},  {"b7", 14 * 14, 480, 80, 20, 1, 2}, {"b10", 14 * 14, 672, 112, 28, 1, 2},
         {"b13", 49, 1152, 192, 48, 1, 1},    {"b16", 49, 1152, 320, 48, 0, 1}};
     hipStream_t s; CK(hipStreamCreate(&s));
@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
         float* w1t = dalloc<float>(size_t(sh.R) * sh.K, 0.05f);
         float* b1 = dalloc<float>(sh.R, 0.1f);
         float* w2 = dalloc<float>(size_t(sh.R) * sh.K, 0.05f);
+        float* w2c = dalloc<float>(size_t(sh.R + 4) * sh.K, 0.05f);
         float* b2 = dalloc<float>(sh.K, 0.1f);
         float* gate = dalloc<float>(size_t(n) * sh.K, 0.f);
         T* res = dalloc<T>(size_t(n) * sh.HW * sh.N, 1.f);
@@ -52,7 +53,7 @@ int main(int argc, char** argv) {
         pa.w1t = w1t; pa.b1 = b1; pa.w2 = w2; pa.b2 = b2; pa.gate = gate; pa.res = sh.res ? res : nullptr; pa.out = out;
         pa.n = n; pa.HW = sh.HW; pa.K = sh.K; pa.N = sh.N; pa.KS = KS; pa.NTILES = NTILES; pa.R = sh.R;
         SeArgs sa{};
-        sa.partial = partial; sa.ntiles = sh.ntiles; sa.inv_hw = pa.inv_hw; sa.w1t = w1t; sa.b1 = b1; sa.w2 = w2; sa.b2 = b2;
+        sa.partial = partial; sa.ntiles = sh.ntiles; sa.inv_hw = pa.inv_hw; sa.w1t = w1t; sa.b1 = b1; sa.w2c = w2c; sa.b2 = b2;
         sa.gate = gate; sa.C = sh.K; sa.R = sh.R; sa.n = n;
         PwArgs wa{};
         wa.a = D; wa.wp = Wp; wa.bias = bias; wa.gate = gate; wa.res = pa.res; wa.out = out; wa.M = n * sh.HW; wa.K = sh.K;
@@ -103,11 +104,23 @@ int main(int argc, char** argv) {
             std::sort(v.begin(), v.end());
             printf(" %s %.2f", names[i], v[v.size() / 2] * 0.01);
         }
+        {
+            CK(hipMemset(d_st, 0, 8 * 4096 * sizeof(long long)));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(whenet_stamps), &d_st, sizeof(d_st)));
+            launch_se(sa, s);
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(whenet_stamps), &nul, sizeof(nul)));
+            std::vector<long long> ss(8 * 64);
+            CK(hipMemcpy(ss.data(), d_st, ss.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            const char* sn[] = {"entry", "issue+squeeze", "barrier", "fc1", "barrier", "excite"};
+            printf("\n   SE wg0:");
+            for (int i = 1; i <= 5; ++i) printf(" %s %.2f", sn[i], (ss[i] - ss[i - 1]) * 0.01);
+        }
         std::vector<long long> starts;
         for (int b = 0; b < nb; ++b) starts.push_back(st[b * 8] - t0);
         std::sort(starts.begin(), starts.end());
         printf("  | last workgroup starts +%.2f us\n", starts.back() * 0.01);
-        for (void* p : {(void*)D, (void*)Wp, (void*)bias, (void*)partial, (void*)w1t, (void*)b1, (void*)w2, (void*)b2,
+        for (void* p : {(void*)D, (void*)Wp, (void*)bias, (void*)partial, (void*)w1t, (void*)b1, (void*)w2, (void*)w2c, (void*)b2,
                         (void*)gate, (void*)res, (void*)out})
             CK(hipFree(p));
     }
