@@ -169,6 +169,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enq = time.perf_counter() - t0          # host time to enqueue the K steps (must stay below el)
     torch.cuda.synchronize()
     fence()
     el = time.perf_counter() - t0
@@ -235,6 +236,7 @@ def main():
     out = {
         "metric": "head crops/sec (224x224)", "value": value, "unit": "crops/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "host_enqueue_ms_per_step": enq / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": f"batch={B}/GPU 224x224 uint8 crops resident in HBM -> angles+argmax+logits "
