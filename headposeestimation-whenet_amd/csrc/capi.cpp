@@ -145,6 +145,28 @@ int whenet_submit_u8(whenet_t* h, const uint8_t* crops, int n, int* ticket) {
     return guarded(h, [&](whenet::Engine& e) { *ticket = e.submit(crops, n); });
 }
 
+int whenet_frame_rects(int frame_h, int frame_w, const float* bboxes, int k, int32_t* rects) {
+    if (frame_h <= 0 || frame_w <= 0 || k < 0 || (k > 0 && (bboxes == nullptr || rects == nullptr))) return WHENET_EINVAL;
+    for (int i = 0; i < k; ++i) whenet::frame_box_rect(frame_h, frame_w, bboxes + 4 * i, rects + 4 * i);
+    return WHENET_OK;
+}
+
+int whenet_submit_frame(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
+                        const int32_t* rects, int k, int* ticket) {
+    if (ticket == nullptr || (channel_order != WHENET_RGB && channel_order != WHENET_BGR)) return WHENET_EINVAL;
+    return guarded(h, [&](whenet::Engine& e) {
+        *ticket = e.submit_frame(frame, frame_h, frame_w, channel_order == WHENET_BGR, rects, k);
+    });
+}
+
+int whenet_op_crop_resize(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
+                          const int32_t* rects, int k, uint8_t* crops) {
+    if (channel_order != WHENET_RGB && channel_order != WHENET_BGR) return WHENET_EINVAL;
+    return guarded(h, [&](whenet::Engine& e) {
+        e.op_crop_resize(frame, frame_h, frame_w, channel_order == WHENET_BGR, rects, k, crops);
+    });
+}
+
 int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits) {
     return guarded(h, [&](whenet::Engine& e) { e.collect(ticket, ypr, argmax, logits); });
 }

@@ -159,6 +159,10 @@ Engine::~Engine() {
         if (s.d_ypr) (void)hipFree(s.d_ypr);
         if (s.d_amax) (void)hipFree(s.d_amax);
         if (s.d_logits) (void)hipFree(s.d_logits);
+        if (s.h_frame) (void)hipHostFree(s.h_frame);
+        if (s.d_frame) (void)hipFree(s.d_frame);
+        if (s.h_plan) (void)hipHostFree(s.h_plan);
+        if (s.d_plan) (void)hipFree(s.d_plan);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
     }
@@ -737,6 +741,103 @@ void Engine::collect(int ticket, float* ypr, int32_t* argmax, float* logits) {
     if (argmax) std::memcpy(argmax, slot->h_amax, N * 3 * sizeof(int32_t));
     if (logits) std::memcpy(logits, slot->h_logits, N * N_LOGITS * sizeof(float));
     slot->busy = false;
+}
+
+Engine::Slot* Engine::free_slot() {
+    for (Slot& s : slots_)
+        if (!s.busy) return &s;
+    throw Error(WHENET_EINVAL, "too many submissions in flight (collect one first)");
+}
+
+void Engine::ensure_slot_frame(Slot& s, size_t frame_bytes, int k) {
+    if (frame_bytes > s.frame_cap) {
+        if (s.h_frame) (void)hipHostFree(s.h_frame);
+        if (s.d_frame) (void)hipFree(s.d_frame);
+        s.h_frame = nullptr; s.d_frame = nullptr; s.frame_cap = 0;
+        WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_frame), frame_bytes, hipHostMallocDefault));
+        WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_frame), frame_bytes));
+        s.frame_cap = frame_bytes;
+    }
+    if (k > s.plan_cap) {
+        if (s.h_plan) (void)hipHostFree(s.h_plan);
+        if (s.d_plan) (void)hipFree(s.d_plan);
+        s.h_plan = nullptr; s.d_plan = nullptr; s.plan_cap = 0;
+        const size_t bytes = size_t(k) * CROP_PLAN_INTS * sizeof(int32_t);
+        WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_plan), bytes, hipHostMallocDefault));
+        WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_plan), bytes));
+        s.plan_cap = k;
+    }
+}
+
+namespace {
+void check_rects(int fh, int fw, const int32_t* rects, int k) {
+    for (int i = 0; i < k; ++i) {
+        const int32_t* r = rects + 4 * i;
+        WHENET_REQUIRE(r[0] >= 0 && r[1] >= 0 && r[2] <= fh && r[3] <= fw && r[0] < r[2] && r[1] < r[3], WHENET_EINVAL,
+                       "crop window " + std::to_string(i) + " is empty or outside the frame");
+    }
+}
+}  // namespace
+
+// One frame of demo_video.py:49-58 as ONE submission: the frame crosses PCIe once; every head is
+// cropped / colour-swapped / resized on the device (frame.hip) straight into the forward's input.
+int Engine::submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(frame != nullptr && fh > 0 && fw > 0 && k >= 0 && (k == 0 || rects != nullptr), WHENET_EINVAL,
+                   "submit_frame: bad arguments");
+    check_rects(fh, fw, rects, k);
+    Slot* slot = free_slot();
+    if (k > 0) {
+        ensure_capacity(k);
+        ensure_slot(*slot, k);
+        const size_t fbytes = size_t(fh) * fw * 3;
+        ensure_slot_frame(*slot, fbytes, k);
+        std::memcpy(slot->h_frame, frame, fbytes);
+        for (int i = 0; i < k; ++i) build_crop_plan(rects + 4 * i, slot->h_plan + size_t(i) * CROP_PLAN_INTS);
+        const size_t N = size_t(k);
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_frame, slot->h_frame, fbytes, hipMemcpyHostToDevice, copy_stream_));
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_plan, slot->h_plan, N * CROP_PLAN_INTS * sizeof(int32_t),
+                                        hipMemcpyHostToDevice, copy_stream_));
+        WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream_));
+        WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
+        launch_crop_resize(slot->d_frame, fw, swap_rb, slot->d_plan, k, slot->d_in, stream_);
+        run_forward(slot->d_in, k, slot->d_ypr, slot->d_amax, slot->d_logits, stream_);
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_ypr, slot->d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_amax, slot->d_amax, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_logits, slot->d_logits, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    } else {
+        ensure_slot(*slot, 1);
+    }
+    WHENET_HIP_CHECK(hipEventRecord(slot->done, stream_));
+    slot->busy = true;
+    slot->n = k;
+    slot->ticket = next_ticket_++;
+    return slot->ticket;
+}
+
+void Engine::op_crop_resize(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k,
+                            uint8_t* crops_out) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(frame != nullptr && rects != nullptr && crops_out != nullptr && fh > 0 && fw > 0 && k > 0,
+                   WHENET_EINVAL, "op_crop_resize: bad arguments");
+    check_rects(fh, fw, rects, k);
+    std::vector<int32_t> plan(size_t(k) * CROP_PLAN_INTS);
+    for (int i = 0; i < k; ++i) build_crop_plan(rects + 4 * i, plan.data() + size_t(i) * CROP_PLAN_INTS);
+    const size_t fbytes = size_t(fh) * fw * 3, obytes = size_t(k) * IN_BYTES;
+    uint8_t* d_frame = static_cast<uint8_t*>(dev_alloc(fbytes));
+    int32_t* d_plan = static_cast<int32_t*>(dev_alloc(plan.size() * sizeof(int32_t)));
+    uint8_t* d_out = static_cast<uint8_t*>(dev_alloc(obytes));
+    try {
+        WHENET_HIP_CHECK(hipMemcpy(d_frame, frame, fbytes, hipMemcpyHostToDevice));
+        WHENET_HIP_CHECK(hipMemcpy(d_plan, plan.data(), plan.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        launch_crop_resize(d_frame, fw, swap_rb, d_plan, k, d_out, stream_);
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+        WHENET_HIP_CHECK(hipMemcpy(crops_out, d_out, obytes, hipMemcpyDeviceToHost));
+    } catch (...) {
+        dev_free(d_frame); dev_free(d_plan); dev_free(d_out);
+        throw;
+    }
+    dev_free(d_frame); dev_free(d_plan); dev_free(d_out);
 }
 
 // Per-launch timing of the forward AS THE TIMED PATH RUNS IT: the same sub-batch chains on the

@@ -72,6 +72,9 @@ class Engine {
                         hipStream_t stream);
     void sync();
     int submit(const uint8_t* crops, int n);
+    int submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k);
+    void op_crop_resize(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k,
+                        uint8_t* crops_out);
     void collect(int ticket, float* ypr, int32_t* argmax, float* logits);
     int profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap);
 
@@ -99,6 +102,11 @@ class Engine {
         int32_t *h_amax = nullptr, *d_amax = nullptr;
         float *h_logits = nullptr, *d_logits = nullptr;
         hipEvent_t copied = nullptr, done = nullptr;
+        // frame submissions: the frame and the crop plans travel instead of the crops
+        size_t frame_cap = 0;
+        uint8_t *h_frame = nullptr, *d_frame = nullptr;
+        int plan_cap = 0;
+        int32_t *h_plan = nullptr, *d_plan = nullptr;
     };
 
     template <typename T> T* upload(const std::vector<T>& v);
@@ -125,6 +133,8 @@ class Engine {
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
+    void ensure_slot_frame(Slot& s, size_t frame_bytes, int k);
+    Slot* free_slot();
 
     int device_ = 0, dtype_ = WHENET_F32, num_cus_ = 256;
     bool use_graph_ = true;

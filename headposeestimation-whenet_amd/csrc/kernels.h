@@ -151,6 +151,15 @@ struct FrontArgs {
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);
 
+// ---- frame.hip --------------------------------------------------------------------------
+// Per-head pre-processing of a frame (demo_video.py:13-24): bbox margins -> crop window ->
+// (BGR->RGB) -> cv2.resize-compatible fixed-point bilinear to 224x224 uint8.
+constexpr int CROP_PLAN_INTS = 8 + 6 * IMG;     // header {y0,x0,h,w,area2x,xmax,-,-} + xofs|a0|a1|yofs|b0|b1
+void frame_box_rect(int frame_h, int frame_w, const float bbox[4], int32_t rect[4]);
+void build_crop_plan(const int32_t rect[4], int32_t* plan);
+void launch_crop_resize(const uint8_t* d_frame, int fw, int swap_rb, const int32_t* d_plan, int k, uint8_t* d_out,
+                        hipStream_t stream);
+
 // ---- tail.hip ---------------------------------------------------------------------------
 // Blocks 7..16 + head conv + GAP + Dense + decode as ONE launch, one workgroup per crop.
 struct TailBlock {

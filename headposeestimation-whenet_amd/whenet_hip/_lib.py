@@ -46,6 +46,9 @@ _PROTOS = {
     "whenet_sync": (C.c_int, [_P]),
     "whenet_submit_u8": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "whenet_collect": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "whenet_frame_rects": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P]),
+    "whenet_submit_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "whenet_op_crop_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "whenet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
     "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
@@ -81,6 +84,26 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+RGB, BGR = 0, 1
+
+
+def _frame_u8(frame) -> np.ndarray:
+    frame = np.asarray(frame)
+    if frame.ndim != 3 or frame.shape[2] != 3 or frame.dtype != np.uint8:
+        raise ValueError(f"frame must be uint8 [H,W,3], got {frame.dtype} {frame.shape}")
+    return np.ascontiguousarray(frame)
+
+
+def frame_rects(frame_h: int, frame_w: int, bboxes) -> np.ndarray:
+    """demo_video.py:13-21 for k YOLO boxes (y_min, x_min, y_max, x_max) -> int32 [k,4] windows
+    (y0, x0, y1, x1).  Pure host arithmetic inside the library (no GPU needed)."""
+    b = np.ascontiguousarray(bboxes, np.float32).reshape(-1, 4)
+    out = np.empty((b.shape[0], 4), np.int32)
+    code = load().whenet_frame_rects(int(frame_h), int(frame_w), _ptr(b), b.shape[0], _ptr(out))
+    raise_for(code, "whenet_frame_rects: bad arguments")
+    return out
 
 
 class WhenetError(RuntimeError):
@@ -160,6 +183,23 @@ class Handle:
         t = C.c_int(-1)
         self._check(self._lib.whenet_submit_u8(self._h, _ptr(crops), crops.shape[0], C.byref(t)))
         return t.value
+
+    def submit_frame(self, frame: np.ndarray, rects: np.ndarray, bgr: bool = True) -> int:
+        """frame uint8 [H,W,3]; rects int32 [k,4] (y0,x0,y1,x1) -> ticket (collect with n=k)."""
+        frame = _frame_u8(frame)
+        rects = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+        t = C.c_int(-1)
+        self._check(self._lib.whenet_submit_frame(self._h, _ptr(frame), frame.shape[0], frame.shape[1],
+                                                  BGR if bgr else RGB, _ptr(rects), rects.shape[0], C.byref(t)))
+        return t.value
+
+    def op_crop_resize(self, frame: np.ndarray, rects: np.ndarray, bgr: bool = True) -> np.ndarray:
+        frame = _frame_u8(frame)
+        rects = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+        out = np.empty((rects.shape[0], 224, 224, 3), np.uint8)
+        self._check(self._lib.whenet_op_crop_resize(self._h, _ptr(frame), frame.shape[0], frame.shape[1],
+                                                    BGR if bgr else RGB, _ptr(rects), rects.shape[0], _ptr(out)))
+        return out
 
     def collect(self, ticket: int, n: int, want_logits: bool = False):
         ypr = np.empty((n, 3), np.float32)

@@ -42,3 +42,20 @@ def scene_crops(n: int, seed: int = 0) -> np.ndarray:
         img += rng.normal(0, rng.uniform(0.0, 0.06), size=img.shape)   # sensor noise
         out[i] = np.clip(np.rint(img * 255), 0, 255).astype(np.uint8)
     return out
+
+
+def video_frame(h: int = 720, w: int = 1280, seed: int = 7) -> np.ndarray:
+    """A seeded BGR 'video frame' (smooth gradients + noise), uint8 [h,w,3]."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) % 256)], axis=-1)
+    return (base.astype(np.int32) + rng.integers(-20, 21, base.shape)).clip(0, 255).astype(np.uint8)
+
+
+def head_boxes(k: int, h: int = 720, w: int = 1280, seed: int = 11) -> np.ndarray:
+    """k seeded YOLO-style boxes (y_min, x_min, y_max, x_max), float32, inside an h x w frame."""
+    rng = np.random.default_rng(seed)
+    size = rng.uniform(0.06, 0.3, k) * h
+    cy = rng.uniform(0.0, 1.0, k) * (h - size)
+    cx = rng.uniform(0.0, 1.0, k) * (w - size * 0.8)
+    return np.stack([cy, cx, cy + size, cx + size * 0.8], axis=1).astype(np.float32)

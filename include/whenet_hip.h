@@ -130,6 +130,30 @@ WHENET_API int whenet_sync(whenet_t* h);
 WHENET_API int whenet_submit_u8(whenet_t* h, const uint8_t* crops, int n, int* ticket);
 WHENET_API int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits);
 
+/* ---- per-frame pre-processing on the device: replaces the host work of
+ * process_detection (demo_video.py:13-24) and crop_and_pred (demo.py:8-11) for ALL heads of a
+ * frame, and the per-head get_angle calls of demo_video.py:56-58, by one submission.
+ *
+ * whenet_frame_rects: the bbox margin arithmetic of demo_video.py:13-19 (float32, as YOLO's boxes
+ * are; y_max / x_max use the already-moved y_min / x_min) followed by the int() truncation and
+ * slice clipping of demo_video.py:21.  bboxes [k,4] = (y_min, x_min, y_max, x_max) as
+ * YOLO.detect returns them; rects [k,4] = (y0, x0, y1, x1), the window img[y0:y1, x0:x1].
+ * Pure host arithmetic, no GPU needed.  (demo.py:9-10 uses its integer bbox as the window directly.) */
+#define WHENET_RGB 0            /* frame is already RGB            (demo.py:8 converts first)       */
+#define WHENET_BGR 1            /* frame is BGR as cv2 delivers it (demo_video.py:22 swaps per crop) */
+WHENET_API int whenet_frame_rects(int frame_h, int frame_w, const float* bboxes, int k, int32_t* rects);
+/* frame uint8 [frame_h, frame_w, 3] (host).  Copies the frame into pinned memory and enqueues
+ * H2D(frame) -> crop + colour order + cv2.resize-compatible bilinear to [k,224,224,3] on the device
+ * -> forward -> D2H of the results; whenet_collect(ticket, ...) returns the k heads' outputs in
+ * rect order.  k = 0 (no head in the frame) is valid.  An empty or out-of-frame window is
+ * WHENET_EINVAL (cv2.resize raises on an empty source). */
+WHENET_API int whenet_submit_frame(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
+                        const int32_t* rects, int k, int* ticket);
+/* the crop/resize kernel alone (host pointers): crops uint8 [k,224,224,3] RGB, exactly the array
+ * get_angle would have been handed */
+WHENET_API int whenet_op_crop_resize(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
+                          const int32_t* rects, int k, uint8_t* crops);
+
 /* ---- measurement: run `iters` eager forwards of `n` device-resident crops exactly as the
  * timed path runs them (same concurrent sub-batch chains, same streams) with ONE HIP event
  * recorded on the chain's stream between consecutive kernel launches; a launch's time is
