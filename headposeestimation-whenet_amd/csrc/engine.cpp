@@ -166,7 +166,7 @@ Engine::~Engine() {
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, se_counter_, in_u8_, o_ypr_, o_amax_, o_logits_};
+    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, in_u8_, o_ypr_, o_amax_, o_logits_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
@@ -184,15 +184,6 @@ void Engine::set_option(const std::string& key, long value) {
     } else if (key == "pw_impl") {
         WHENET_REQUIRE(value == 0 || value == 1, WHENET_EINVAL, "pw_impl must be 0 (MFMA) or 1 (check kernel)");
         pw_impl_ = int(value);
-        sync();
-        drop_graphs();
-    } else if (key == "fuse_se") {
-        fuse_se_ = value != 0;
-        sync();
-        drop_graphs();
-    } else if (key == "fuse_project") {
-        WHENET_REQUIRE(value >= 0 && value <= 17, WHENET_EINVAL, "fuse_project must be 0 (off) or a first block index 1..17");
-        fuse_project_from_ = int(value);
         sync();
         drop_graphs();
     } else if (key == "fuse_front") {
@@ -241,8 +232,8 @@ void Engine::get_info(whenet_info_t* out) const {
             const bool has_expand = b.spec.expand != 1;
             const bool front = fuse_front_ && has_expand;
             k += front ? 1 : (has_expand ? 2 : 1);
-            const bool proj = fuse_project_from_ > 0 && idx >= fuse_project_from_ && pw_impl_ == 0 && !(front && fuse_se_);
-            k += (proj || (front && fuse_se_)) ? 1 : 2;
+            (void)front;
+            k += 2;
         }
         if (tail_fused_) k = k - 2 + 1;
         out->n_kernels_per_forward = k;
@@ -265,7 +256,7 @@ void Engine::drop_graphs() {
 
 void Engine::release_arena() {
     void** arena[] = {&x0_, &x1_, &e_, &d_, &hc_, reinterpret_cast<void**>(&partial_), reinterpret_cast<void**>(&gate_),
-                      reinterpret_cast<void**>(&se_counter_), reinterpret_cast<void**>(&in_u8_), reinterpret_cast<void**>(&o_ypr_),
+                      reinterpret_cast<void**>(&in_u8_), reinterpret_cast<void**>(&o_ypr_),
                       reinterpret_cast<void**>(&o_amax_), reinterpret_cast<void**>(&o_logits_)};
     for (void** p : arena) {
         if (*p) (void)hipFree(*p);
@@ -300,8 +291,6 @@ void Engine::ensure_capacity(int n) {
     hc_ = alloc(N * HC_ELEMS * es);
     partial_ = static_cast<float*>(alloc(N * partial_per_crop_ * sizeof(float)));
     gate_ = static_cast<float*>(alloc(N * 1152 * sizeof(float)));
-    se_counter_ = static_cast<int*>(alloc(N * sizeof(int)));
-    WHENET_HIP_CHECK(hipMemset(se_counter_, 0, N * sizeof(int)));
     in_u8_ = static_cast<uint8_t*>(alloc(N * IN_BYTES));
     o_ypr_ = static_cast<float*>(alloc(N * 3 * sizeof(float)));
     o_amax_ = static_cast<int32_t*>(alloc(N * 3 * sizeof(int32_t)));
@@ -355,6 +344,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const void* dw_in = in;
     int se_ntiles = b.dw.plan.ntiles();
     const bool fused = fuse_front_ && sp.has_expand() && pw_impl_ == 0;
+    bool se_in_front = false;
     if (fused) {
         FrontArgs a{};
         a.x = in;
@@ -363,7 +353,10 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.wd = b.dw.w;
         a.bd = b.dw.bias;
         a.out = v.d;
-        a.partial = v.partial;
+        a.rpart = v.partial;
+        se_in_front = b.se.C >= 480;         // blocks 7-16: the SE reduce conv moves into the front kernel
+        a.w1t = se_in_front ? b.se.w1t : nullptr;
+        a.R = b.se.R;
         a.k = sp.k;
         a.s = sp.s;
         a.H = sp.h_in;
@@ -377,15 +370,6 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.plan = b.fplan;
         a.plan.threads = front_threads(b.fplan, n);
         se_ntiles = b.fplan.ntiles();
-        if (fuse_se_) {
-            a.se.counter = v.counter;
-            a.se.w1t = b.se.w1t;
-            a.se.b1 = b.se.b1;
-            a.se.w2 = b.se.w2;
-            a.se.b2 = b.se.b2;
-            a.se.gate = v.gate;
-            a.se.R = b.se.R;
-        }
         R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s, a.plan.threads).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
           [&] { launch_front(a, dtype_, s); });
@@ -425,37 +409,24 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         R(p + "/dw", "dw", kernel_name_dw(dtype_, sp.k, sp.s), double(n) * (hw_in + hw_out) * cexp * es,
           2.0 * n * hw_out * sp.k * sp.k * cexp, [&] { launch_dw(a, dtype_, s); });
     }
-    const bool proj_fused = fuse_project_from_ > 0 && sp.index >= fuse_project_from_ && pw_impl_ == 0 &&
-                            !(fused && fuse_se_);
-    if (proj_fused) {
-        ProjectArgs a{};
-        a.d = v.d;
-        a.wp = b.project.wp;
-        a.bias = b.project.bias;
-        a.partial = v.partial;
-        a.ntiles = se_ntiles;
+    if (se_in_front) {
+        // the front kernel already applied se_reduce to its channel sums (v.partial holds the
+        // (tiles x chunks) partial vectors of every crop): finish the SEBlock
+        SeExciteArgs a{};
+        a.rpart = v.partial;
+        a.np = se_ntiles * b.fplan.chunks;
         a.inv_hw = 1.0f / float(hw_out);
-        a.w1t = b.se.w1t;
         a.b1 = b.se.b1;
-        a.w2 = b.se.w2;
+        a.w2c = b.se.w2c;
         a.b2 = b.se.b2;
         a.gate = v.gate;
-        a.res = sp.has_skip() ? in : nullptr;
-        a.out = out;
-        a.n = n;
-        a.HW = hw_out;
-        a.K = b.project.K;
-        a.N = b.project.N;
-        a.KS = b.project.KS;
-        a.NTILES = b.project.NTILES;
+        a.C = b.se.C;
         a.R = b.se.R;
-        R(p + "/project", "proj", kernel_name_project(a, dtype_).c_str(),
-          double(n) * hw_out * (a.K + a.N + (sp.has_skip() ? a.N : 0)) * es + double(n) * (a.ntiles + 1) * a.K * 4.0 +
-              2.0 * a.K * a.R * 4.0,
-          2.0 * n * hw_out * a.K * a.N + 4.0 * n * a.K * a.R, [&] { launch_project(a, dtype_, s); });
-        return;
-    }
-    if (!(fused && fuse_se_)) {
+        a.n = n;
+        R(p + "/se", "se", ("whenet_se_excite_kernel<" + std::to_string(se_padded_r(a.R)) + ">").c_str(),
+          double(n) * (a.np * se_padded_r(a.R) + a.C) * 4.0 + double(a.C) * se_padded_r(a.R) * 4.0, 2.0 * n * a.C * a.R,
+          [&] { launch_se_excite(a, s); });
+    } else {
         SeArgs a{};
         a.partial = v.partial;
         a.ntiles = se_ntiles;
@@ -575,7 +546,6 @@ Engine::View Engine::view(int crop_off) const {
     v.hc = static_cast<char*>(hc_) + o * HC_ELEMS * es;
     v.partial = partial_ + o * partial_per_crop_;
     v.gate = gate_ + o * 1152;
-    v.counter = se_counter_ + o;
     return v;
 }
 

@@ -120,7 +120,6 @@ class Engine {
     struct View {          // the activation arena as seen by a sub-batch starting at some crop
         void *x0, *x1, *e, *d, *hc;
         float *partial, *gate;
-        int* counter;
     };
     View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
@@ -140,9 +139,6 @@ class Engine {
     bool use_graph_ = true;
     int pw_impl_ = 0;
     int repeat_ = 1;
-    bool fuse_se_ = false;      // option "fuse_se": the front kernel's last workgroup per crop computes the SE gate
-    int fuse_project_from_ = 0; // option "fuse_project": blocks >= this index run SE + project as ONE launch
-                                // (project.hip; 0 = never).  Bitwise equal to the two launches; measured no faster.
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
     bool tail_fused_ = false;   // option "tail": blocks 7..16 + head + heads as ONE launch, one workgroup per crop
                                 // (tail.hip). Correct and tested, but a lone CU needs ~1.1 ms per crop: it only matches
@@ -171,7 +167,6 @@ class Engine {
     size_t arena_bytes_ = 0;
     void *x0_ = nullptr, *x1_ = nullptr, *e_ = nullptr, *d_ = nullptr, *hc_ = nullptr;
     float *partial_ = nullptr, *gate_ = nullptr;
-    int* se_counter_ = nullptr;
     uint8_t* in_u8_ = nullptr;
     float* o_ypr_ = nullptr;
     int32_t* o_amax_ = nullptr;

@@ -24,7 +24,6 @@
 // the grouping of the squeeze-excite partial sums follows this kernel's own tiling.
 #include "device_math.h"
 #include "kernels.h"
-#include "se_device.h"
 #include "stamps.h"
 
 #include <cstdlib>
@@ -42,10 +41,10 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                                                             const float* __restrict__ be,
                                                             const float* __restrict__ wd,
                                                             const float* __restrict__ bd, T* __restrict__ out,
-                                                            float* __restrict__ partial, int H, int Ho, int Cin,
+                                                            float* __restrict__ rpart, int H, int Ho, int Cin,
                                                             int Cexp, int pad, int KSe, int NTe, int CC, int TH,
                                                             int NSX, int tiles_x, int EH, int EW, int w_off,
-                                                            FrontSe se) {
+                                                            const float* __restrict__ w1t, int R, int RP) {
     constexpr int V = Vec<T>::V;
     constexpr int SZ = int(sizeof(T));
     using VT = typename Vec<T>::type;
@@ -177,6 +176,18 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         cur = nxt;
     }
     STAMP(2);
+    // first W1V reduce-kernel values of this lane's output (used after the taps: see the SE half below)
+    constexpr int W1V = 16;
+    const int fj = tid >> 2, fq = tid & 3;
+    float w1v[W1V];
+    {
+        const float* wrow = w1t + size_t(fj < R ? fj : 0) * Cexp + c0;
+#pragma unroll
+        for (int i = 0; i < W1V; ++i) {
+            const int c = fq + 4 * i;
+            w1v[i] = (w1t != nullptr && fj < R && c < ccur) ? wrow[c] : 0.f;
+        }
+    }
     lds_barrier();
     STAMP(3);
 
@@ -246,51 +257,46 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         for (int v = 0; v < VC; ++v) s_red[sidx * ccur + cg * VC + v] = sum[v];
     }
     lds_barrier();
+    // ---- squeeze-excite, first half: this workgroup's share of the reduce conv ------------------
+    // The tile's channel sums (fixed order) stay on the CU; since se_reduce is linear, the sum over
+    // channels can be taken chunk by chunk and tile by tile: rpart[j] = sum_{c in chunk}
+    // tilesum[c] * W1[c][j].  se.hip adds the (tiles x chunks) partial vectors of a crop in fixed
+    // order, scales by 1/(H*W) and finishes the block.  This spreads the reduce kernel (221 KB for
+    // C = 1152) over every workgroup of the layer instead of streaming it through one CU per crop.
+    float* s_sum = s_w;                                  // the depthwise taps are no longer needed
     if (tid < ccur) {
         float t = 0.0f;
         for (int s = 0; s < NPC; ++s) t += s_red[s * ccur + tid];
-        float* dst = partial + (size_t(b) * gridDim.x + tile) * Cexp + c0 + tid;
-        // with the in-kernel hand-off the sums are stored write-through (sc1): visible device-wide
-        // once drained, no L2 write-back fence needed
-        if (se.counter != nullptr) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *dst = t;
+        if (w1t == nullptr) {
+            // plain form (wide early layers, whose SE kernels are tiny): the tile's channel sums
+            // go to se.hip's full kernel: rpart is [n][ntiles][Cexp] here
+            rpart[(size_t(b) * gridDim.x + tile) * Cexp + c0 + tid] = t;
+        }
+        s_sum[tid] = t;
+    }
+    if (w1t == nullptr) return;
+    lds_barrier();
+    {
+        // 4 lanes per output j: lane q sums channels q, q+4, ..; combined (a0+a1)+(a2+a3)
+        const int j = fj, q = fq;
+        float acc = 0.0f;
+        if (j < R) {
+            const float* wrow = w1t + size_t(j) * Cexp + c0;
+#pragma unroll
+            for (int i = 0; i < W1V; ++i) {
+                const int c = q + 4 * i;
+                if (c < ccur) acc = fmaf(s_sum[c], w1v[i], acc);
+            }
+            for (int c = q + 4 * W1V; c < ccur; c += 4) acc = fmaf(s_sum[c], wrow[c], acc);
+        }
+        const float o1 = __shfl_xor(acc, 1, 64);
+        const float pair = (q & 1) ? (o1 + acc) : (acc + o1);          // (a_even + a_odd) on both lanes
+        const float o2 = __shfl_xor(pair, 2, 64);
+        const float tot = (q & 2) ? (o2 + pair) : (pair + o2);         // (a0+a1) + (a2+a3)
+        if (q == 0 && j < RP)
+            rpart[((size_t(b) * gridDim.x + tile) * gridDim.y + blockIdx.y) * RP + j] = (j < R) ? tot : 0.0f;
     }
     STAMP(6);
-    if (se.counter == nullptr) return;             // squeeze-excite runs as its own launch
-
-    // ---- the LAST workgroup of this crop to arrive finishes the block: squeeze-excite gate ------
-    // Hand-off across workgroups (other CUs / XCDs): the partial sums were stored write-through
-    // (sc1), every storing wave drains its stores, then one lane takes a ticket; the last arriver
-    // issues an agent-scope acquire (drops its L1) before any lane reads the other workgroups'
-    // partial sums.  No release fence (an L2 write-back per workgroup costs microseconds).  Nothing
-    // depends on dispatch order or placement.  The counter resets itself for the next launch.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* s_flag = reinterpret_cast<int*>(smem + w_off);        // depthwise taps are no longer needed
-    if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(se.counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_flag = (ticket == int(gridDim.x * gridDim.y) - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (*s_flag == 0) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(se.counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    float* s_mean = reinterpret_cast<float*>(smem);            // [1152]  (the tile region is free)
-    float* s_r = s_mean + 1152;                                // [64]
-    const float* pp = partial + size_t(b) * gridDim.x * Cexp;
-    float* gate_b = se.gate + size_t(b) * Cexp;
-    const float inv_hw = 1.0f / float(Ho * Ho);
-    switch ((se.R + 3) & ~3) {
-        case 4: se_gate_device<4, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
-        case 8: se_gate_device<8, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
-        case 12: se_gate_device<12, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
-        case 20: se_gate_device<20, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
-        case 28: se_gate_device<28, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
-        default: se_gate_device<48, NTHR>(pp, int(gridDim.x), inv_hw, se.w1t, se.b1, se.w2, se.b2, gate_b, Cexp, se.R, s_mean, s_r, tid); break;
-    }
 }
 
 template <typename T, int K, int S, int NTHR>
@@ -307,8 +313,8 @@ void launch_t(const FrontArgs& a, hipStream_t stream) {
     }
     hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
-                       static_cast<T*>(a.out), a.partial, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
-                       p.tiles_x, p.EH, p.EW, p.w_off, a.se);
+                       static_cast<T*>(a.out), a.rpart, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
+                       p.tiles_x, p.EH, p.EW, p.w_off, a.w1t, a.R, (a.R + 3) & ~3);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 

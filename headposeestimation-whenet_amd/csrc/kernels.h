@@ -60,6 +60,20 @@ struct SeArgs {
     int C, R, n;
 };
 void launch_se(const SeArgs& a, hipStream_t stream);
+// second half of the SEBlock when the producer (front.hip) already applied the reduce conv to its
+// channel sums: r = swish(b1 + sum of the crop's np partial vectors / (H*W)) -> excite -> sigmoid
+struct SeExciteArgs {
+    const float* rpart;    // [n][np][RP]
+    int np;
+    float inv_hw;
+    const float* b1;       // [R]
+    const float* w2c;      // [C][RP]
+    const float* b2;       // [C]
+    float* gate;           // [n][C]
+    int C, R, n;
+};
+void launch_se_excite(const SeExciteArgs& a, hipStream_t stream);
+int se_excite_split(int C);     // workgroups per crop
 int se_padded_r(int R);
 
 // ---- pw.hip -----------------------------------------------------------------------------
@@ -77,25 +91,6 @@ struct PwArgs {
     int M, K, N, KS, NTILES, HW, act;
 };
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream);
-
-// ---- project.hip ------------------------------------------------------------------------
-// SE gate + gated project conv + BN (+ skip) as one launch: every workgroup recomputes its crop's
-// gate from the tile partial sums (bitwise the arithmetic of launch_se + launch_pw).
-struct ProjectArgs {
-    const void* d;         // [n][HW][K] T   depthwise output
-    const void* wp;        // packed MFMA operand image of the project conv
-    const float* bias;     // [N]
-    const float* partial;  // [n][ntiles][K] tile partial sums of d
-    int ntiles;
-    float inv_hw;
-    const float *w1t, *b1, *w2, *b2;   // SE kernels as in SeArgs
-    float* gate;           // [n][K] (written by the first workgroup of each crop) or nullptr
-    const void* res;       // [n][HW][N] T or nullptr
-    void* out;             // [n][HW][N] T
-    int n, HW, K, N, KS, NTILES, R;
-};
-void launch_project(const ProjectArgs& a, int dtype, hipStream_t stream);
-std::string kernel_name_project(const ProjectArgs& a, int dtype);
 
 // ---- head.hip ---------------------------------------------------------------------------
 // GlobalAveragePooling2D + Dense(120|66|66) + softmax-expectation decode + argmax
@@ -129,13 +124,6 @@ struct FrontPlan {
 };
 FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp);
 int front_threads(const FrontPlan& p, int n);    // lanes per workgroup for a launch of n crops (256 | 512)
-// squeeze-excite finished inside the front kernel by the crop's last workgroup (counter != nullptr)
-struct FrontSe {
-    int* counter = nullptr;      // [n] arrival tickets, zero between launches (self-resetting)
-    const float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
-    float* gate = nullptr;       // [n][Cexp]
-    int R = 0;
-};
 struct FrontArgs {
     const void* x;         // [n,H,H,Cin] T  block input
     const void* wep;       // packed expand weights (MFMA fragment order)
@@ -143,10 +131,12 @@ struct FrontArgs {
     const float* wd;       // [k*k][Cexp]
     const float* bd;       // [Cexp]
     void* out;             // [n,Ho,Ho,Cexp] T
-    float* partial;        // [n][ntiles][Cexp]
+    float* rpart;          // w1t != NULL: [n][ntiles][chunks][RP] this workgroup's share of the SE reduce conv
+                           // (unscaled);  w1t == NULL: [n][ntiles][Cexp] the tile's channel sums (for launch_se)
+    const float* w1t;      // [R][Cexp] se_reduce kernel, transposed, or NULL
+    int R;
     int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
     FrontPlan plan;
-    FrontSe se;
 };
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);

@@ -158,6 +158,82 @@ __global__ __launch_bounds__(1024) void whenet_se_kernel(const float* __restrict
     STAMP(5);
 }
 
+// Second half of the SEBlock for blocks whose producer (front.hip) already applied the reduce conv
+// to its tile/chunk channel sums: r[j] = swish(b1[j] + (sum over the crop's np partial vectors) /
+// (H*W)); gate[c] = sigmoid(b2[c] + sum_j r[j] * W2[j][c]).  SPLIT workgroups per crop each take a
+// channel slice (one CU streams ~50 GB/s: 221 KB of excite kernel for C = 1152 is spread over 4).
+// The partial vectors and the lane's excite row are independent loads: one memory round trip.
+template <int RP>
+__global__ __launch_bounds__(256) void whenet_se_excite_kernel(const float* __restrict__ rpart, int np, float inv_hw,
+                                                               const float* __restrict__ b1,
+                                                               const float* __restrict__ w2c,
+                                                               const float* __restrict__ b2, float* __restrict__ gate,
+                                                               int C, int R, int SPLIT) {
+    constexpr int NTHR = 256;
+    constexpr int NCI = 2;                            // channels per lane (slice <= 512)
+    __shared__ float s_r[RP];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / SPLIT, slice = blockIdx.x - b * SPLIT;
+    const int per = (C + SPLIT - 1) / SPLIT;
+    const int c_lo = slice * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
+    STAMP(0);
+
+    // excite rows of this lane's channels (independent of the data)
+    float wv[NCI][RP];
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci) {
+        const int c = c_lo + tid + ci * NTHR;
+        const float4v* wrow = reinterpret_cast<const float4v*>(w2c + size_t(c < c_hi ? c : c_lo) * RP);
+#pragma unroll
+        for (int j = 0; j < RP; j += 4) {
+            const float4v v = wrow[j >> 2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[ci][j + q] = v[q];
+        }
+    }
+    // r[j]: 4 running sums over the partial vectors p = u mod 4, combined (t0+t1)+(t2+t3)
+    if (tid < RP) {
+        const float* pp = rpart + size_t(b) * np * RP + tid;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < np; p += 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = (p + u < np) ? pp[size_t(p + u) * RP] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (p + u < np) t[u & 3] += x[u];
+        }
+        const float r = ((t[0] + t[1]) + (t[2] + t[3])) * inv_hw;
+        s_r[tid] = (tid < R) ? swish_f<true>(r + b1[tid]) : 0.f;
+    }
+    STAMP(1);
+    lds_barrier();
+    STAMP(2);
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci) {
+        const int c = c_lo + tid + ci * NTHR;
+        if (c < c_hi) {
+            float t0 = b2[c], t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < RP; j += 4) {
+                t0 = fmaf(s_r[j], wv[ci][j], t0);
+                t1 = fmaf(s_r[j + 1], wv[ci][j + 1], t1);
+                t2 = fmaf(s_r[j + 2], wv[ci][j + 2], t2);
+                t3 = fmaf(s_r[j + 3], wv[ci][j + 3], t3);
+            }
+            gate[size_t(b) * C + c] = sigmoid_f<true>((t0 + t1) + (t2 + t3));
+        }
+    }
+    STAMP(3);
+}
+
+template <int RP>
+void launch_ex(const SeExciteArgs& a, hipStream_t stream) {
+    const int split = se_excite_split(a.C);
+    hipLaunchKernelGGL(whenet_se_excite_kernel<RP>, dim3(a.n * split), dim3(256), 0, stream, a.rpart, a.np, a.inv_hw,
+                       a.b1, a.w2c, a.b2, a.gate, a.C, a.R, split);
+}
+
 template <int RP>
 void launch_rp(const SeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(whenet_se_kernel<RP>, dim3(a.n), dim3(1024), 0, stream, a.partial, a.ntiles, a.inv_hw, a.w1t,
@@ -167,6 +243,24 @@ void launch_rp(const SeArgs& a, hipStream_t stream) {
 }  // namespace
 
 int se_padded_r(int R) { return (R + 3) & ~3; }
+
+// excite workgroups per crop: a 256-lane workgroup covers <= 512 channels, and wide layers are
+// split further so that no CU streams more than ~64 KB of excite kernel
+int se_excite_split(int C) { return C > 768 ? 4 : (C > 288 ? 2 : 1); }
+
+void launch_se_excite(const SeExciteArgs& a, hipStream_t stream) {
+    WHENET_REQUIRE(a.C <= 1152 && a.np >= 1, WHENET_EINVAL, "squeeze-excite: bad shape");
+    switch (se_padded_r(a.R)) {
+        case 4: launch_ex<4>(a, stream); break;
+        case 8: launch_ex<8>(a, stream); break;
+        case 12: launch_ex<12>(a, stream); break;
+        case 20: launch_ex<20>(a, stream); break;
+        case 28: launch_ex<28>(a, stream); break;
+        case 48: launch_ex<48>(a, stream); break;
+        default: throw Error(WHENET_EINVAL, "squeeze-excite: unsupported reduced width");
+    }
+    WHENET_HIP_CHECK(hipGetLastError());
+}
 
 void launch_se(const SeArgs& a, hipStream_t stream) {
     WHENET_REQUIRE(a.C <= 1152, WHENET_EINVAL, "squeeze-excite: C > 1152");

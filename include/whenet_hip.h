@@ -93,12 +93,6 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
  *          "fuse_front" (0/1, default 1: expand 1x1 + depthwise as ONE kernel per block, the
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
- *          "fuse_se" (0/1, default 0: 1 = the fused kernel's last workgroup per crop also computes
- *                  the squeeze-excite gate (write-through partial sums + ticket + agent-scope
- *                  acquire); measured slower than the separate 1024-lane SE launch),
- *          "fuse_project" (0..17, default 0: blocks with index >= value run squeeze-excite + project
- *                  conv as ONE launch, each workgroup recomputing its crop's gate; bitwise equal to
- *                  the two launches, measured no faster at any batch; 0 = never),
  *          "tail" (0/1, default 0: 1 = blocks 7..16 + head + heads as ONE launch, one workgroup
  *                  per crop; 0 = one launch per layer),
  *          "lanes" (1..8, default 4: concurrent sub-batch chains per forward),

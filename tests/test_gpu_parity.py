@@ -96,25 +96,11 @@ def test_mbconv_block_kernels(handle, taps, index):
         assert rel_err(r0["dw"], taps[f"{p}/dw"]) < 2 * t, "dw (unfused)"
         assert rel_err(r0["out"], taps[f"{p}/out"]) < 3 * t, "out (unfused)"
     r = handle.op_block(index, x.astype(np.float32))
-    # option fuse_project: SE gate + project GEMM as ONE launch (project.hip) must give the same
-    # gate and block output bitwise as the default two launches (se.hip + pw.hip)
-    handle.set_option("fuse_project", 1)
-    try:
-        r2 = handle.op_block(index, x.astype(np.float32))
-    finally:
-        handle.set_option("fuse_project", 0)
-    assert np.array_equal(r["gate"], r2["gate"]), "gate: fused SE+project differs from se.hip"
-    assert np.array_equal(r["out"], r2["out"]), "out: fused SE+project differs from se.hip + pw.hip"
     if b.has_expand:
         assert np.array_equal(r["dw"], r0["dw"]), "fused expand+depthwise differs from pw+dw"
-        # option fuse_se: squeeze-excite finished by the front kernel's last workgroup per crop
-        # (agent-scope hand-off) must equal the separate SE launch bitwise
-        handle.set_option("fuse_se", 1)
-        try:
-            r1 = handle.op_block(index, x.astype(np.float32))
-        finally:
-            handle.set_option("fuse_se", 0)
-        assert np.array_equal(r["gate"], r1["gate"]) and np.array_equal(r["out"], r1["out"])
+        # the fused kernel also applies the SE reduce conv to its channel sums (another summation
+        # order than se.hip's): same gate and block output within the kernel tolerance
+        assert rel_err(r["gate"], r0["gate"]) < 2 * t and rel_err(r["out"], r0["out"]) < 3 * t
     # the stages below consume the kernel's own upstream output, so errors chain a little
     assert rel_err(r["dw"], taps[f"{p}/dw"]) < 2 * t, "dw"
     assert rel_err(r["gate"], taps[f"{p}/gate"].reshape(r["gate"].shape)) < 2 * t, "gate"

@@ -50,7 +50,10 @@ int main(int argc, char** argv) {
         a.wd = dalloc<float>(size_t(sh.k) * sh.k * sh.Cexp, 0.1f);
         a.bd = dalloc<float>(sh.Cexp, 0.1f);
         a.out = dalloc<T>(size_t(n) * Ho * Ho * sh.Cexp, 0.f);
-        a.partial = dalloc<float>(size_t(n) * a.plan.ntiles() * sh.Cexp, 0.f);
+        a.rpart = dalloc<float>(size_t(n) * a.plan.ntiles() * sh.Cexp, 0.f);
+        a.R = std::max(1, sh.Cin / 4);
+        const float* w1_all = dalloc<float>(size_t(a.R) * sh.Cexp, 0.05f);
+        a.w1t = sh.Cexp >= 480 ? w1_all : nullptr;       // engine.cpp: SE reduce conv in the front kernel for blocks 7-16
 
         auto time_loop = [&](auto&& fn, int iters) {
             for (int i = 0; i < 5; ++i) fn();
@@ -80,7 +83,7 @@ int main(int argc, char** argv) {
         printf("%-4s thr=%d k%d s%d H%d Cexp%d n=%d: %.2f us (%.0f GB/s alg) | plan CC=%d TH=%d NSX=%d tiles=%dx%d chunks=%d E=%dx%d lds=%zu | %d wgs, span %.2f us\n",
                sh.name, thr, sh.k, sh.s, sh.H, sh.Cexp, n, t_front, bytes / t_front * 1e-3, p.CC, p.TH, p.NSX, p.tiles_x, p.tiles_y,
                p.chunks, p.EH, p.EW, p.lds_bytes, nb, (tend - t0) * 0.01);
-        const char* names[] = {"entry", "zero+w", "expand", "sync", "taps", "store", "sums"};
+        const char* names[] = {"entry", "zero+w", "expand", "sync", "taps", "store", "sums+fc1"};
         printf("   median:");
         for (int i = 1; i <= 6; ++i) {
             std::vector<long long> v;
@@ -95,7 +98,7 @@ int main(int argc, char** argv) {
         printf(" | wg total median %.2f max %.2f | starts: median +%.2f last +%.2f us\n", total[nb / 2] * 0.01,
                total.back() * 0.01, starts[nb / 2] * 0.01, starts.back() * 0.01);
         for (const void* q : {a.x, a.wep, (const void*)a.be, (const void*)a.wd, (const void*)a.bd, (const void*)a.out,
-                              (const void*)a.partial})
+                              (const void*)a.rpart, (const void*)w1_all})
             CK(hipFree(const_cast<void*>(q)));
     }
     return 0;
