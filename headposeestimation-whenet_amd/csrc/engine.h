@@ -145,8 +145,8 @@ class Engine {
                                 // the per-layer schedule at batch >= 256, so it is off by default.
     TailBlock tail_host_[10];   // block descriptors of blocks 7..16 (host copy + device table)
     TailBlock* d_tail_blocks_ = nullptr;    // blocks 7..16 + head + heads as one launch (option "tail")
-    int lanes_ = 4;             // concurrent sub-batch chains per forward (option "lanes")
-    int min_lane_crops_ = 8;    // do not split below this many crops per chain
+    int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")
+    int min_lane_crops_ = 16;   // do not split below this many crops per chain
     std::vector<hipStream_t> lane_streams_;
     std::vector<hipEvent_t> join_ev_;
     hipEvent_t fork_ev_ = nullptr;

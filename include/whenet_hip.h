@@ -95,7 +95,7 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
  *          "tail" (0/1, default 0: 1 = blocks 7..16 + head + heads as ONE launch, one workgroup
  *                  per crop; 0 = one launch per layer),
- *          "lanes" (1..8, default 4: concurrent sub-batch chains per forward),
+ *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
 WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
 
