@@ -68,7 +68,9 @@ def main():
                     x = taps["stem"] if b.index == 1 else taps[f"b{b.index - 1}/out"]
                     r = h.op_block(b.index, x.astype(np.float32))
                     parts = []
-                    if b.has_expand:
+                    if b.has_expand and impl == 1:
+                        # (with the MFMA path the expand conv is fused into the front kernel: the
+                        # expanded tensor only exists in LDS, there is nothing to compare)
                         parts.append("exp %.2e" % rel(r["expand"], taps[f"{p}/expand"])[0])
                     parts.append("dw %.2e" % rel(r["dw"], taps[f"{p}/dw"])[0])
                     parts.append("gate %.2e" % rel(r["gate"], taps[f"{p}/gate"].reshape(r["gate"].shape))[0])
