@@ -3,13 +3,33 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <new>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "engine.h"
 
+// A handle = one primary engine plus, with option "inflight" > 1, replica engines (own streams,
+// activation arena, hipGraphs and a copy of the 8.6-17 MB device weights).  A forward is a chain of
+// 51 dependent launches -- about half of a batch-64 forward is launch latency -- so independent
+// forwards are spread round-robin over the engines and overlap on the GPU.
+constexpr int MAX_INFLIGHT_ENGINES = 4;
 struct whenet_ctx {
-    whenet::Engine* engine = nullptr;
+    whenet::Engine* engine = nullptr;                            // primary: op_*, profile, blocking forward
+    std::vector<whenet::Engine*> replicas;                       // engines 1..inflight-1
+    std::vector<char> snapshot;
+    int device_id = 0, dtype = WHENET_F32;
+    int inflight = 1;
+    size_t next = 0;                                             // round-robin cursor
+    std::vector<std::pair<std::string, long>> options;           // replayed on new replicas
+    whenet::Engine& at(size_t i) { return i == 0 ? *engine : *replicas[i - 1]; }
+    whenet::Engine& take() {
+        whenet::Engine& e = at(next % size_t(inflight));
+        next = (next + 1) % size_t(inflight);
+        return e;
+    }
 };
 
 namespace {
@@ -44,6 +64,9 @@ int create_impl(const void* blob, size_t nbytes, int device_id, int dtype, whene
         std::unique_ptr<whenet::Engine> e(new whenet::Engine(blob, nbytes, device_id, dtype));
         whenet_t* h = new whenet_t;
         h->engine = e.release();
+        h->snapshot.assign(static_cast<const char*>(blob), static_cast<const char*>(blob) + nbytes);
+        h->device_id = device_id;
+        h->dtype = dtype;
         *out = h;
         return WHENET_OK;
     } catch (const whenet::Error& e) {
@@ -103,6 +126,7 @@ int whenet_create_from_memory(const void* snapshot, size_t nbytes, int device_id
 void whenet_destroy(whenet_t* h) {
     if (h == nullptr) return;
     try {
+        for (whenet::Engine* e : h->replicas) delete e;
         delete h->engine;
     } catch (...) {
     }
@@ -122,7 +146,34 @@ int whenet_get_info(const whenet_t* h, whenet_info_t* out) {
 
 int whenet_set_option(whenet_t* h, const char* key, long value) {
     if (key == nullptr) return WHENET_EINVAL;
-    return guarded(h, [&](whenet::Engine& e) { e.set_option(key, value); });
+    return guarded(h, [&](whenet::Engine& e) {
+        const std::string k = key;
+        if (k == "inflight") {
+            WHENET_REQUIRE(value >= 1 && value <= MAX_INFLIGHT_ENGINES, WHENET_EINVAL, "inflight must be 1..4");
+            e.release_aux_streams();
+            for (whenet::Engine* r : h->replicas) r->release_aux_streams();
+            while (int(h->replicas.size()) + 1 > value) {
+                delete h->replicas.back();
+                h->replicas.pop_back();
+            }
+            while (int(h->replicas.size()) + 1 < value) {
+                std::unique_ptr<whenet::Engine> r(
+                    new whenet::Engine(h->snapshot.data(), h->snapshot.size(), h->device_id, h->dtype));
+                for (const auto& kv : h->options) r->set_option(kv.first, kv.second);
+                h->replicas.push_back(r.release());
+            }
+            h->inflight = int(value);
+            h->next = 0;
+            // several forwards in flight: each runs as ONE chain, the concurrency comes from the others
+            const long lanes = value > 1 ? 1 : 3;
+            e.set_option("lanes", lanes);
+            for (whenet::Engine* r : h->replicas) r->set_option("lanes", lanes);
+            return;
+        }
+        e.set_option(k, value);
+        for (whenet::Engine* r : h->replicas) r->set_option(k, value);
+        h->options.emplace_back(k, value);
+    });
 }
 
 int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits) {
@@ -132,17 +183,26 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
 int whenet_forward_u8_device(whenet_t* h, const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax,
                              float* d_logits, void* stream) {
     return guarded(h, [&](whenet::Engine& e) {
-        e.forward_device(d_crops, n, d_ypr, d_argmax, d_logits, static_cast<hipStream_t>(stream));
+        // caller's stream: strictly ordered on it (primary engine); handle-owned streams: next engine
+        whenet::Engine& eng = (stream != nullptr) ? e : h->take();
+        eng.forward_device(d_crops, n, d_ypr, d_argmax, d_logits, static_cast<hipStream_t>(stream));
     });
 }
 
 int whenet_sync(whenet_t* h) {
-    return guarded(h, [&](whenet::Engine& e) { e.sync(); });
+    return guarded(h, [&](whenet::Engine& e) {
+        e.sync();
+        for (whenet::Engine* r : h->replicas) r->sync();
+    });
 }
 
+// tickets of the pinned pipeline carry the engine index in their low bits
 int whenet_submit_u8(whenet_t* h, const uint8_t* crops, int n, int* ticket) {
     if (ticket == nullptr) return WHENET_EINVAL;
-    return guarded(h, [&](whenet::Engine& e) { *ticket = e.submit(crops, n); });
+    return guarded(h, [&](whenet::Engine&) {
+        const size_t idx = h->next % size_t(h->inflight);
+        *ticket = h->take().submit(crops, n) * MAX_INFLIGHT_ENGINES + int(idx);
+    });
 }
 
 int whenet_frame_rects(int frame_h, int frame_w, const float* bboxes, int k, int32_t* rects) {
@@ -154,8 +214,10 @@ int whenet_frame_rects(int frame_h, int frame_w, const float* bboxes, int k, int
 int whenet_submit_frame(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
                         const int32_t* rects, int k, int* ticket) {
     if (ticket == nullptr || (channel_order != WHENET_RGB && channel_order != WHENET_BGR)) return WHENET_EINVAL;
-    return guarded(h, [&](whenet::Engine& e) {
-        *ticket = e.submit_frame(frame, frame_h, frame_w, channel_order == WHENET_BGR, rects, k);
+    return guarded(h, [&](whenet::Engine&) {
+        const size_t idx = h->next % size_t(h->inflight);
+        *ticket = h->take().submit_frame(frame, frame_h, frame_w, channel_order == WHENET_BGR, rects, k) *
+                      MAX_INFLIGHT_ENGINES + int(idx);
     });
 }
 
@@ -168,12 +230,19 @@ int whenet_op_crop_resize(whenet_t* h, const uint8_t* frame, int frame_h, int fr
 }
 
 int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits) {
-    return guarded(h, [&](whenet::Engine& e) { e.collect(ticket, ypr, argmax, logits); });
+    return guarded(h, [&](whenet::Engine&) {
+        const int idx = ticket % MAX_INFLIGHT_ENGINES;
+        WHENET_REQUIRE(ticket >= 0 && idx < h->inflight, WHENET_EINVAL, "unknown ticket " + std::to_string(ticket));
+        h->at(size_t(idx)).collect(ticket / MAX_INFLIGHT_ENGINES, ypr, argmax, logits);
+    });
 }
 
 int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap,
                    int* count) {
     return guarded(h, [&](whenet::Engine& e) {
+        // one engine, alone on the GPU: per-launch figures comparable with rocprofv3's kernel trace
+        // (which serialises concurrent work); with "inflight" > 1 the timed path overlaps such chains
+        for (whenet::Engine* r : h->replicas) r->sync();
         const int c = e.profile(d_crops, n, iters, stats, cap);
         if (count) *count = c;
     });

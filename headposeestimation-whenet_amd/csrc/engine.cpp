@@ -1,6 +1,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace whenet {
@@ -87,14 +88,14 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
     num_cus_ = prop_.multiProcessorCount;
 
     WHENET_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    WHENET_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    // Only the main stream exists up front: the runtime places a new stream on its least-loaded
+    // hardware queue (4 of them), so streams are created in the order concurrency needs them -- the
+    // main streams of the engines of one handle, then sub-batch lanes / the copy stream on first use --
+    // instead of nine per engine, most of them idle ballast that skews that placement.
     WHENET_HIP_CHECK(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
     for (int i = 0; i < MAX_LANES - 1; ++i) {
-        hipStream_t st = nullptr;
         hipEvent_t ev = nullptr;
-        WHENET_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         WHENET_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        lane_streams_.push_back(st);
         join_ev_.push_back(ev);
     }
 
@@ -536,6 +537,33 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
     }
 }
 
+hipStream_t Engine::lane_stream(int i) {
+    while (int(lane_streams_.size()) <= i) {
+        hipStream_t st = nullptr;
+        WHENET_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        lane_streams_.push_back(st);
+    }
+    return lane_streams_[size_t(i)];
+}
+
+// Drop the on-demand streams (and the graphs that reference them): called before a handle creates
+// more engines, so that the new engines' main streams are placed on hardware queues as on a fresh
+// process instead of behind this engine's idle lane / copy streams.
+void Engine::release_aux_streams() {
+    DeviceGuard guard(device_);
+    sync();
+    drop_graphs();
+    for (hipStream_t st : lane_streams_) (void)hipStreamDestroy(st);
+    lane_streams_.clear();
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    copy_stream_ = nullptr;
+}
+
+hipStream_t Engine::copy_stream() {
+    if (!copy_stream_) WHENET_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    return copy_stream_;
+}
+
 Engine::View Engine::view(int crop_off) const {
     const size_t o = size_t(crop_off), es = esz();
     View v;
@@ -565,7 +593,7 @@ void Engine::enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_
     int off = 0;
     for (int i = 0; i < lanes; ++i) {
         const int cnt = n / lanes + (i < n % lanes ? 1 : 0);
-        hipStream_t st = (i == 0) ? s : lane_streams_[size_t(i - 1)];
+        hipStream_t st = (i == 0) ? s : lane_stream(i - 1);
         if (i > 0) WHENET_HIP_CHECK(hipStreamWaitEvent(st, fork_ev_, 0));
         enqueue_forward(view(off), d_in + size_t(off) * IN_BYTES, cnt, d_ypr + size_t(off) * 3,
                         d_amax ? d_amax + size_t(off) * 3 : nullptr, d_logits ? d_logits + size_t(off) * N_LOGITS : nullptr,
@@ -591,6 +619,11 @@ void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_am
             drop_graphs();
         }
         hipGraph_t graph = nullptr;
+        {   // the lane streams this batch will fork into exist before the capture starts
+            int lanes = lanes_;
+            while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
+            if (lanes > 1) (void)lane_stream(lanes - 2);
+        }
         WHENET_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
         try {
             enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
@@ -638,7 +671,7 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
 void Engine::sync() {
     DeviceGuard guard(device_);
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(copy_stream_));
+    if (copy_stream_) WHENET_HIP_CHECK(hipStreamSynchronize(copy_stream_));
     for (hipStream_t st : lane_streams_) WHENET_HIP_CHECK(hipStreamSynchronize(st));
 }
 
@@ -685,8 +718,8 @@ int Engine::submit(const uint8_t* crops, int n) {
     ensure_slot(*slot, n);
     const size_t N = size_t(n);
     std::memcpy(slot->h_in, crops, N * IN_BYTES);
-    WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream_));
-    WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream_));
+    WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream()));
+    WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream()));
     WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
     run_forward(slot->d_in, n, slot->d_ypr, slot->d_amax, slot->d_logits, stream_);
     WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_ypr, slot->d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -765,10 +798,10 @@ int Engine::submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, cons
         std::memcpy(slot->h_frame, frame, fbytes);
         for (int i = 0; i < k; ++i) build_crop_plan(rects + 4 * i, slot->h_plan + size_t(i) * CROP_PLAN_INTS);
         const size_t N = size_t(k);
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_frame, slot->h_frame, fbytes, hipMemcpyHostToDevice, copy_stream_));
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_frame, slot->h_frame, fbytes, hipMemcpyHostToDevice, copy_stream()));
         WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_plan, slot->h_plan, N * CROP_PLAN_INTS * sizeof(int32_t),
-                                        hipMemcpyHostToDevice, copy_stream_));
-        WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream_));
+                                        hipMemcpyHostToDevice, copy_stream()));
+        WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream()));
         WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
         launch_crop_resize(slot->d_frame, fw, swap_rb, slot->d_plan, k, slot->d_in, stream_);
         run_forward(slot->d_in, k, slot->d_ypr, slot->d_amax, slot->d_logits, stream_);
@@ -842,7 +875,7 @@ int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat
         int off = 0;
         for (int i = 0; i < lanes; ++i) {
             const int cnt = n / lanes + (i < n % lanes ? 1 : 0);
-            hipStream_t st = (i == 0) ? stream_ : lane_streams_[size_t(i - 1)];
+            hipStream_t st = (i == 0) ? stream_ : lane_stream(i - 1);
             if (i > 0) WHENET_HIP_CHECK(hipStreamWaitEvent(st, fork_ev_, 0));
             LaunchRecorder& lr = recs[size_t(i)];
             lr.cursor = 0;

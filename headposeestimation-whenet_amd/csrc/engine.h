@@ -71,6 +71,7 @@ class Engine {
     void forward_device(const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax, float* d_logits,
                         hipStream_t stream);
     void sync();
+    void release_aux_streams();
     int submit(const uint8_t* crops, int n);
     int submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k);
     void op_crop_resize(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k,
@@ -132,6 +133,8 @@ class Engine {
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
+    hipStream_t lane_stream(int i);     // created on first use
+    hipStream_t copy_stream();          // created on first use
     void ensure_slot_frame(Slot& s, size_t frame_bytes, int k);
     Slot* free_slot();
 

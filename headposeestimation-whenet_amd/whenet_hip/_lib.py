@@ -157,6 +157,12 @@ class Handle:
             self._lib.whenet_destroy(self._h)
             self._h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
         try:
             self.close()

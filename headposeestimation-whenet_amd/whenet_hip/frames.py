@@ -40,6 +40,9 @@ class FramePipeline:
         if not 1 <= depth <= MAX_INFLIGHT:
             raise ValueError(f"depth must be 1..{MAX_INFLIGHT}")
         self._h = model._handle
+        # `depth` frames in flight = `depth` engines behind the handle (own streams / arena / graphs):
+        # frame i+1's staging, crop and forward overlap frame i's on the GPU
+        self._h.set_option("inflight", min(depth, 4))
         self._depth = depth
         self._bgr = bool(bgr)
         self._pending: Deque[Tuple[int, np.ndarray]] = deque()

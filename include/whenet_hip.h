@@ -96,6 +96,12 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "tail" (0/1, default 0: 1 = blocks 7..16 + head + heads as ONE launch, one workgroup
  *                  per crop; 0 = one launch per layer),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
+ *          "inflight" (1..4, default 1: n > 1 gives the handle n engines -- own streams, activation
+ *                  arena, graphs, replicated weights -- and spreads whenet_forward_u8_device calls with
+ *                  stream == NULL and whenet_submit_* calls over them round-robin, each forward as
+ *                  one chain; independent forwards then overlap on the GPU (a forward is a chain of 51
+ *                  dependent launches).  The caller gives every forward in flight its own output
+ *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
  *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
 WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
 
@@ -110,8 +116,9 @@ WHENET_API int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n,
                       float* ypr, int32_t* argmax, float* logits);
 
 /* Device-pointer form: all pointers are device memory on the handle's GPU; the work is
- * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream) and the call returns
- * without waiting.  This is the form bench.py times (inputs resident in HBM). */
+ * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream, or with option "inflight"
+ * > 1 the next of the handle's engines) and the call returns without waiting.  This is the form
+ * bench.py times (inputs resident in HBM). */
 WHENET_API int whenet_forward_u8_device(whenet_t* h, const uint8_t* d_crops, int n,
                              float* d_ypr, int32_t* d_argmax, float* d_logits, void* stream);
 WHENET_API int whenet_sync(whenet_t* h);

@@ -313,3 +313,34 @@ def test_snapshot_file_roundtrip(weights_file, golden):
     y, p, r = m.get_angle(golden["crops"][:2])
     assert np.abs(np.stack([y, p, r], 1) - golden["expected"]["angles"][:2]).max() < F32_DEG
     m.close()
+
+
+@pytest.mark.gpu
+def test_forwards_in_flight_are_bitwise_identical(blob, golden):
+    """option inflight: n engines behind one handle, used round-robin; every engine must produce the
+    bits of the single-engine handle, through the device-pointer form and the pinned pipeline."""
+    import torch
+    crops = golden["crops"]
+    n = crops.shape[0]
+    with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+        ref = h.forward(crops, want_logits=True)
+        h.set_option("inflight", 3)
+        assert h.forward(crops, want_logits=True)[0].tobytes() == ref[0].tobytes()
+        dev = torch.device("cuda:0")
+        d_crops = torch.from_numpy(crops).to(dev)
+        outs = [(torch.zeros((n, 3), device=dev), torch.zeros((n, 3), dtype=torch.int32, device=dev),
+                 torch.zeros((n, 252), device=dev)) for _ in range(6)]
+        for y, a, l in outs:                                  # 6 forwards over 3 engines, all in flight
+            h.forward_device(d_crops.data_ptr(), n, y.data_ptr(), a.data_ptr(), l.data_ptr())
+        h.sync()
+        for y, a, l in outs:
+            assert np.array_equal(y.cpu().numpy(), ref[0]) and np.array_equal(a.cpu().numpy(), ref[1])
+            assert np.array_equal(l.cpu().numpy(), ref[2])
+        tickets = [h.submit(crops[i:i + 3]) for i in range(0, 6, 3)] + [h.submit(crops)]
+        got = [h.collect(t, k, want_logits=True) for t, k in zip(tickets, (3, 3, n))]
+        assert np.array_equal(got[0][0], ref[0][:3]) and np.array_equal(got[1][0], ref[0][3:6])
+        assert np.array_equal(got[2][2], ref[2])
+        with pytest.raises(ValueError):
+            h.set_option("inflight", 9)
+        h.set_option("inflight", 1)
+        assert h.forward(crops)[0].tobytes() == ref[0].tobytes()

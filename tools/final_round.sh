@@ -16,5 +16,5 @@ timeout 300 python bench.py --batch 8 --no-cpu-baseline --no-latency > $R/gpurun
 timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-latency > $R/gpurun_out/final/bench_f16_b1.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/final/rocprof_stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -o bench -- python $R/bench.py --no-cpu-baseline --no-latency > $R/gpurun_out/final/rocprof_bench.json 2>/dev/null; echo "rocprof exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -o bench -- python $R/bench.py --no-cpu-baseline --no-latency --no-serial > $R/gpurun_out/final/rocprof_bench.json 2>/dev/null; echo "rocprof exit $?"
 cd $R && python tools/gpu_diag.py --quick > $R/gpurun_out/final/diag.txt 2>&1; echo "diag exit $?"
