@@ -28,6 +28,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 namespace whenet {
 
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                                                             const float* __restrict__ bd, T* __restrict__ out,
                                                             float* __restrict__ rpart, int H, int Ho, int Cin,
                                                             int Cexp, int pad, int KSe, int NTe, int CC, int TH,
-                                                            int NSX, int tiles_x, int EH, int EW, int w_off,
+                                                            int NSX, int tiles_x, int EH, int EW, int EP, int w_off,
                                                             const float* __restrict__ w1t, int R, int RP) {
     constexpr int V = Vec<T>::V;
     constexpr int SZ = int(sizeof(T));
@@ -66,7 +67,6 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     const int c0 = blockIdx.y * CC;
     const int ccur = (Cexp - c0 < CC) ? (Cexp - c0) : CC;
     const int b = blockIdx.z;
-    const int EP = CC * SZ + 16;
     const int oy0 = tyi * TH, ox0 = txi * NSX * P;
     const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
 
@@ -314,7 +314,7 @@ void launch_t(const FrontArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
                        static_cast<T*>(a.out), a.rpart, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
-                       p.tiles_x, p.EH, p.EW, p.w_off, a.w1t, a.R, (a.R + 3) & ~3);
+                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
@@ -342,13 +342,72 @@ void launch_thr(const FrontArgs& a, hipStream_t stream) {
 // Tile-shape search (same idea as plan_dw): chunk width CC (multiples of 32, or the whole
 // layer), TH output rows, NSX 7-pixel strips; 256 lanes; LDS <= 64 KiB.  Score = useful lanes x
 // halo efficiency (also the expand recompute factor) x occupancy.
-FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
+namespace {
+
+// LDS cycles per depthwise tap read of one wave-instruction, averaged over the lane groups of the
+// 256 tap lanes, for pixel pitch EP (MI355X_MICROARCH.md, LDS: ds_read_b64 = 2 groups of 32 lanes,
+// ds_read_b128 = 4 groups of 16 lanes in a fixed interleave; bank = (addr / 4) mod 64; a group costs
+// as many cycles as its busiest bank has distinct dwords).  1.0 = conflict-free.
+double tap_read_conflicts(int SZ, int cc, int TH, int NSX, int EW, int s, int EP) {
+    static const int g128[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    const int CG = cc / VC, bytes = VC * SZ, ngroups = (bytes == 16) ? 4 : 2, glanes = 64 / ngroups;
+    double total = 0.0;
+    int counted = 0;
+    for (int wave = 0; wave < 4; ++wave) {
+        for (int g = 0; g < ngroups; ++g) {
+            int seen[64][16];
+            int nseen[64] = {};
+            bool any = false;
+            for (int l = 0; l < glanes; ++l) {
+                const int lane = (bytes == 16) ? g128[g][l] : g * 32 + l;
+                const int tid = wave * 64 + lane;
+                const int cg = tid % CG, sidx = tid / CG;
+                if (sidx >= TH * NSX) continue;
+                const int ty = sidx / NSX, sx = sidx - ty * NSX;
+                const int addr = ((ty * s) * EW + sx * P * s) * EP + cg * bytes;
+                any = true;
+                for (int d = 0; d < bytes; d += 4) {
+                    const int dw = (addr + d) / 4, bank = dw % 64;
+                    bool dup = false;
+                    for (int i = 0; i < nseen[bank]; ++i) dup = dup || seen[bank][i] == dw;
+                    if (!dup && nseen[bank] < 16) seen[bank][nseen[bank]++] = dw;
+                }
+            }
+            if (!any) continue;
+            int worst = 1;
+            for (int b = 0; b < 64; ++b) worst = nseen[b] > worst ? nseen[b] : worst;
+            total += worst;
+            ++counted;
+        }
+    }
+    return counted ? total / counted : 1.0;
+}
+
+// pixel pitch: the channels alone, or 16 bytes of padding when that has fewer tap-read bank
+// conflicts (larger paddings remove the conflicts of the stride-2 layers too, but cost a workgroup
+// per CU in LDS: measured slower)
+int choose_pitch(int SZ, int cc, int TH, int NSX, int EW, int s) {
+    const double c0 = tap_read_conflicts(SZ, cc, TH, NSX, EW, s, cc * SZ);
+    const double c16 = tap_read_conflicts(SZ, cc, TH, NSX, EW, s, cc * SZ + 16);
+    return (c0 <= c16 + 1e-9) ? cc * SZ : cc * SZ + 16;
+}
+
+}  // namespace
+
+// Every tile plan that fits: chunk width CC (multiples of 32, or the whole layer), TH output rows,
+// NSX 7-pixel strips; 256 tap lanes; LDS <= 64 KiB.  `score` is the a-priori figure of merit used
+// for shapes outside the tuned table: useful tap lanes x halo efficiency (also the expand
+// recompute factor) x occupancy.
+std::vector<FrontPlan> plan_front_candidates(int dtype, int k, int s, int H, int Ho, int Cexp,
+                                             std::vector<double>* scores) {
     constexpr int NTHR = 256;           // tap lanes the tile is planned for (the kernel may run more lanes)
     const int SZ = (dtype == WHENET_F16) ? 2 : 4;
     WHENET_REQUIRE(Cexp % VC == 0 && Ho % P == 0, WHENET_EINVAL, "front: unsupported geometry");
     const int spr = Ho / P;
-    FrontPlan best;
-    double best_score = -1.0;
+    std::vector<FrontPlan> out;
     for (int CC = 32; CC <= 160; CC += 32) {
         int cc = CC;
         if (cc > Cexp) cc = Cexp;
@@ -368,7 +427,7 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
                 if (TH * NSX > NS) continue;
                 const int TW = NSX * P;
                 const int EH = (TH - 1) * s + k, EW = (TW - 1) * s + k;
-                const int EP = cc * SZ + 16;
+                const int EP = choose_pitch(SZ, cc, TH, NSX, EW, s);
                 size_t tile_bytes = size_t(EH) * EW * EP;
                 const size_t red_bytes = size_t(NTHR) * VC * 4;              // [NTHR/CG][cc] floats
                 if (red_bytes > tile_bytes) tile_bytes = red_bytes;
@@ -383,27 +442,53 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
                 if (blocks_cu > 8) blocks_cu = 8;
                 const double waves_cu = double(blocks_cu) * NTHR / 64.0;
                 const double occ = waves_cu >= 16.0 ? 1.0 : waves_cu / 16.0;
-                const double score = lane_use * (0.35 + 0.65 * halo) * (0.4 + 0.6 * occ);
-                if (score > best_score + 1e-9) {
-                    best_score = score;
-                    best.CC = cc;
-                    best.TH = TH;
-                    best.NSX = NSX;
-                    best.tiles_x = spr / NSX;
-                    best.tiles_y = ceil_div(Ho, TH);
-                    best.chunks = chunks;
-                    best.EH = EH;
-                    best.EW = EW;
-                    best.w_off = int(w_off);
-                    best.lds_bytes = lds;
-                }
+                FrontPlan p;
+                p.threads = 256;
+                p.CC = cc;
+                p.TH = TH;
+                p.NSX = NSX;
+                p.tiles_x = spr / NSX;
+                p.tiles_y = ceil_div(Ho, TH);
+                p.chunks = chunks;
+                p.EH = EH;
+                p.EW = EW;
+                p.EP = EP;
+                p.w_off = int(w_off);
+                p.lds_bytes = lds;
+                out.push_back(p);
+                if (scores) scores->push_back(lane_use * (0.35 + 0.65 * halo) * (0.4 + 0.6 * occ));
             }
         }
     }
-    WHENET_REQUIRE(best_score > 0, WHENET_EINVAL, "front: no tile plan fits");
     (void)H;
-    best.threads = 256;
-    return best;
+    return out;
+}
+
+namespace {
+// Plans measured on MI355X for EfficientNet-B0's fifteen f16 layer shapes (tools/probes/
+// front_tune.hip: every candidate timed at 64 and 16 crops per launch; profiles/r01/
+// front_tune_f16.txt).  The a-priori score above ranks candidates of one layer in roughly the
+// right order but cannot see tail quantisation or the per-workgroup fixed costs.
+struct TunedPlan { int k, s, H, Cexp, CC, TH, NSX; };
+const TunedPlan TUNED_F16[] = {
+#include "front_tuned_f16.inc"
+};
+}  // namespace
+
+FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
+    std::vector<double> scores;
+    const std::vector<FrontPlan> cand = plan_front_candidates(dtype, k, s, H, Ho, Cexp, &scores);
+    WHENET_REQUIRE(!cand.empty(), WHENET_EINVAL, "front: no tile plan fits");
+    if (dtype == WHENET_F16 && !getenv("WHENET_FRONT_NO_TUNED")) {
+        for (const TunedPlan& t : TUNED_F16)
+            if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp)
+                for (const FrontPlan& p : cand)
+                    if (p.CC == t.CC && p.TH == t.TH && p.NSX == t.NSX) return p;
+    }
+    size_t best = 0;
+    for (size_t i = 1; i < cand.size(); ++i)
+        if (scores[i] > scores[best] + 1e-9) best = i;
+    return cand[best];
 }
 
 // Lanes per workgroup for a launch of n crops.  The tile (and every result bit) is the same either

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -118,11 +119,14 @@ struct FrontPlan {
     int TH = 1, NSX = 1;   // output tile: TH rows x 7*NSX columns
     int tiles_x = 1, tiles_y = 1, chunks = 1;
     int EH = 0, EW = 0;    // LDS tile of the expanded input (with halo)
+    int EP = 0;            // pixel pitch of that tile in bytes (channels + bank-conflict padding)
     int w_off = 0;         // byte offset of the depthwise taps in LDS
     size_t lds_bytes = 0;
     int ntiles() const { return tiles_x * tiles_y; }
 };
 FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp);
+std::vector<FrontPlan> plan_front_candidates(int dtype, int k, int s, int H, int Ho, int Cexp,
+                                             std::vector<double>* scores);
 int front_threads(const FrontPlan& p, int n);    // lanes per workgroup for a launch of n crops (256 | 512)
 struct FrontArgs {
     const void* x;         // [n,H,H,Cin] T  block input
