@@ -427,7 +427,9 @@ std::vector<FrontPlan> plan_front_candidates(int dtype, int k, int s, int H, int
                 if (TH * NSX > NS) continue;
                 const int TW = NSX * P;
                 const int EH = (TH - 1) * s + k, EW = (TW - 1) * s + k;
-                const int EP = choose_pitch(SZ, cc, TH, NSX, EW, s);
+                const int EP_model = choose_pitch(SZ, cc, TH, NSX, EW, s);
+                for (int pad = 0; pad <= 48; pad += 16) {
+                const int EP = cc * SZ + pad;
                 size_t tile_bytes = size_t(EH) * EW * EP;
                 const size_t red_bytes = size_t(NTHR) * VC * 4;              // [NTHR/CG][cc] floats
                 if (red_bytes > tile_bytes) tile_bytes = red_bytes;
@@ -456,7 +458,9 @@ std::vector<FrontPlan> plan_front_candidates(int dtype, int k, int s, int H, int
                 p.w_off = int(w_off);
                 p.lds_bytes = lds;
                 out.push_back(p);
-                if (scores) scores->push_back(lane_use * (0.35 + 0.65 * halo) * (0.4 + 0.6 * occ));
+                // (pitches other than the bank model's choice are candidates for the tuner only)
+                if (scores) scores->push_back(EP == EP_model ? lane_use * (0.35 + 0.65 * halo) * (0.4 + 0.6 * occ) : 0.0);
+                }
             }
         }
     }
@@ -469,7 +473,7 @@ namespace {
 // front_tune.hip: every candidate timed at 64 and 16 crops per launch; profiles/r01/
 // front_tune_f16.txt).  The a-priori score above ranks candidates of one layer in roughly the
 // right order but cannot see tail quantisation or the per-workgroup fixed costs.
-struct TunedPlan { int k, s, H, Cexp, CC, TH, NSX; };
+struct TunedPlan { int k, s, H, Cexp, CC, TH, NSX, pad; };
 const TunedPlan TUNED_F16[] = {
 #include "front_tuned_f16.inc"
 };
@@ -483,7 +487,7 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
         for (const TunedPlan& t : TUNED_F16)
             if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp)
                 for (const FrontPlan& p : cand)
-                    if (p.CC == t.CC && p.TH == t.TH && p.NSX == t.NSX) return p;
+                    if (p.CC == t.CC && p.TH == t.TH && p.NSX == t.NSX && p.EP == t.CC * 2 + t.pad) return p;
     }
     size_t best = 0;
     for (size_t i = 1; i < cand.size(); ++i)

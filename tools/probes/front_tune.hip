@@ -79,13 +79,13 @@ int main() {
             if (rows[i].score > rows[by_score].score) by_score = i;
         printf("%s k%d s%d H%d Cexp%d: %zu candidates; a-priori pick is rank %zu (%.1f / %.1f us)\n", sh.name, sh.k, sh.s, sh.H, sh.Cexp,
                rows.size(), by_score + 1, rows[by_score].t64, rows[by_score].t16);
-        for (size_t i = 0; i < rows.size() && i < 6; ++i)
+        for (size_t i = 0; i < rows.size() && i < 8; ++i)
             printf("   #%zu CC=%3d TH=%2d NSX=%d tiles=%dx%d chunks=%2d lds=%5zu EP=%3d score %.3f : n=64 %7.2f us  n=16 %6.2f us\n", i + 1,
                    rows[i].p.CC, rows[i].p.TH, rows[i].p.NSX, rows[i].p.tiles_x, rows[i].p.tiles_y, rows[i].p.chunks, rows[i].p.lds_bytes,
                    rows[i].p.EP, rows[i].score, rows[i].t64, rows[i].t16);
         char line[160];
-        snprintf(line, sizeof line, "    {%d, %d, %d, %d, %d, %d, %d},   // %s: %.1f us @64, %.1f us @16\n", sh.k, sh.s, sh.H, sh.Cexp,
-                 rows[0].p.CC, rows[0].p.TH, rows[0].p.NSX, sh.name, rows[0].t64, rows[0].t16);
+        snprintf(line, sizeof line, "    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s: %.1f us @64, %.1f us @16\n", sh.k, sh.s, sh.H, sh.Cexp,
+                 rows[0].p.CC, rows[0].p.TH, rows[0].p.NSX, rows[0].p.EP - rows[0].p.CC * 2, sh.name, rows[0].t64, rows[0].t16);
         table += line;
         for (const void* q : {a.x, a.wep, (const void*)a.be, (const void*)a.wd, (const void*)a.bd, (const void*)a.out,
                               (const void*)a.rpart, (const void*)w1_all})
