@@ -577,7 +577,7 @@ Engine::View Engine::view(int crop_off) const {
     return v;
 }
 
-// One forward = up to `lanes_` independent sub-batches, each a 66-kernel chain on its own
+// One forward = up to `lanes_` independent sub-batches, each a 51-kernel chain on its own
 // stream (forked from / joined back into `s` with events, so that under capture they become
 // parallel branches of ONE graph).  Crops are independent, so the split changes nothing in the
 // results; what it buys is overlap: most kernels of this network are short (10-30 us) and

@@ -1,5 +1,5 @@
 // The per-GPU inference engine behind the C ABI: device weights, activation arena, launch
-// schedule of the 66 kernels of one forward, hipGraph cache, per-launch profiling, and the
+// schedule of the 51 kernels of one forward, hipGraph cache, per-launch profiling, and the
 // pinned-buffer submit/collect pipeline.  One engine = one device + one stream; not thread-safe.
 #pragma once
 

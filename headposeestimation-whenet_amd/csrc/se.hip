@@ -16,7 +16,7 @@
 //     combined through LDS in the same fixed order; otherwise a lane issues 16 tiles per trip;
 //   * excite: the se_expand kernel is stored channel-major [C][RP]: a lane's whole row is RP/4
 //     16-byte loads from one 64..192-byte segment (the [R][C] form touched RP pages per wave).
-// The arithmetic and its summation order are those of se_device.h / project.hip.
+// f32 throughout, fixed summation order (bitwise reproducible, independent of the batch).
 #include "device_math.h"
 #include "kernels.h"
 #include "stamps.h"
