@@ -165,6 +165,150 @@ __global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A,
     }
 }
 
+// Register-blocked form of the split-K kernel for deep contractions with MANY rows: a workgroup owns
+// 64 rows x 64 out-channels (2 x 2 MFMA tiles per wave), its 4 waves still split the k-steps
+// interleaved and combine through LDS in wave order -- the partial sums and the order of
+// whenet_pw_kernel<T,1,8,4,..>, so the bits do not change -- but every operand fragment feeds two
+// MFMAs: half the L2 -> CU traffic per flop (the 1 x 1 form re-reads an activation strip once per
+// out-channel tile and a weight tile once per 32 rows: 8x the algorithmic bytes at 64 crops).
+template <typename T, bool GATE, bool RES, int ACT>
+__global__ __launch_bounds__(256, 2) void whenet_pw_split2_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ gate,
+                                                               const T* __restrict__ res, T* __restrict__ out, int M,
+                                                               int K, int N, int KS, int NTILES, int HW, int MT,
+                                                               int NCH) {
+    constexpr int V = Vec<T>::V;
+    using VT = typename Vec<T>::type;
+    constexpr int MB = 2, NT = 2, U = 4, SK = 4;
+    __shared__ float s_red[(SK - 1) * MB * NT * 16 * 64];
+
+    const int id = blockIdx.x;
+    const int q = id >> 3;
+    const int nch = q % NCH;
+    const int mt = (id & 7) + 8 * (q / NCH);
+    if (mt >= MT) return;
+
+    const int lane = threadIdx.x & 63;
+    const int kpart = threadIdx.x >> 6;
+    const int nt0 = nch * NT;
+    const int g = lane >> 5;
+    int row[MB];
+    bool rvalid[MB];
+    const T* ap[MB];
+    const float* gp[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        row[mb] = (mt * MB + mb) * 32 + (lane & 31);
+        rvalid[mb] = row[mb] < M;
+        const int rowc = rvalid[mb] ? row[mb] : (M - 1);
+        ap[mb] = A + size_t(rowc) * K + g * V;
+        gp[mb] = GATE ? gate + size_t(rowc / HW) * K + g * V : nullptr;
+    }
+    const VT* wp = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64 + lane;
+
+    float16v acc[MB][NT];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.0f;
+
+    auto load_a = [&](int mb, int ks) -> VT {
+        VT a = vec_zero<T>();
+        if (rvalid[mb] && ks * 2 * V + g * V < K) {
+            a = *reinterpret_cast<const VT*>(ap[mb] + ks * 2 * V);
+            if constexpr (GATE) {
+                float f[V];
+                vec_to_float<T>(a, f);
+#pragma unroll
+                for (int i = 0; i < V; i += 4) {
+                    const float4v gv = *reinterpret_cast<const float4v*>(gp[mb] + ks * 2 * V + i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[i + j] *= gv[j];
+                }
+                a = float_to_vec<T>(f);
+            }
+        }
+        return a;
+    };
+
+    for (int ks = kpart; ks < KS; ks += U * SK) {
+        VT a[U][MB];
+        VT w[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k1 = ks + u * SK;
+            const VT* wk = wp + size_t(k1) * NTILES * 64;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[u][t] = (k1 < KS && nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[u][mb] = (ks + u * SK < KS) ? load_a(mb, ks + u * SK) : vec_zero<T>();
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nt0 + t < NTILES) Mfma<T>::step(w[u][t], a[u][mb], acc[mb][t]);
+    }
+
+    if (kpart > 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s_red[(((kpart - 1) * MB + mb) * NT + t) * 1024 + r * 64 + lane] = acc[mb][t][r];
+    }
+    lds_barrier();
+    if (kpart > 0) return;
+#pragma unroll 1
+    for (int w = 0; w < SK - 1; ++w)                 // (not unrolled: 64 LDS values in registers at a time)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][t][r] += s_red[((w * MB + mb) * NT + t) * 1024 + r * 64 + lane];
+
+    using OT = T __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        if (!rvalid[mb]) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (nt0 + t >= NTILES) continue;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int n0 = (nt0 + t) * 32 + 8 * qq + 4 * g;
+                if (n0 >= N) continue;
+                const float4v bv = *reinterpret_cast<const float4v*>(bias + n0);
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = acc[mb][t][4 * qq + r] + bv[r];
+                    if constexpr (ACT == ACT_SWISH) y[r] = swish_f<IsF32<T>::value>(y[r]);
+                }
+                if constexpr (RES) {
+                    const OT rv = *reinterpret_cast<const OT*>(res + size_t(row[mb]) * N + n0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] += float(rv[r]);
+                }
+                OT o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = T(y[r]);
+                *reinterpret_cast<OT*>(out + size_t(row[mb]) * N + n0) = o;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Large-M variant.  Same MFMA mapping; what changes is the data movement around it:
 //   * a workgroup owns 128 rows x NT*32 out-channels; the NT weight fragments of a k-step are
@@ -385,6 +529,11 @@ __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restric
     }
 }
 
+// A K >= 320 conv takes the 2 x 2 register-blocked split-K kernel (same bits as the 1 x 1 form) when
+// that still launches enough 64 x 64 workgroups to spread over the chip
+// (>= 128 of them; measured: B=64 +5 %, B=512 +8 %, B <= 16 unchanged)
+bool use_split2(int M, int NTILES) { return ceil_div(M, 64) * ceil_div(NTILES, 2) >= 128; }
+
 struct PwChoice {
     int kind;      // 1 = split-K kernel (whenet_pw_kernel<T,1,8,4,..>), 2 = LDS-staged tile kernel
     int NT, NCH;
@@ -444,6 +593,14 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
     }
     const PwChoice ch = choose_pw(a, num_cus);
     if (ch.kind == 1) {
+        if (use_split2(a.M, a.NTILES)) {
+            const int MT2 = ceil_div(a.M, 64), NCH2 = ceil_div(a.NTILES, 2);
+            hipLaunchKernelGGL((whenet_pw_split2_kernel<T, GATE, RES, ACT>), dim3(8 * ceil_div(MT2, 8) * NCH2), dim3(256),
+                               0, stream, static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, a.gate,
+                               static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES,
+                               a.HW, MT2, NCH2);
+            return;
+        }
         launch_mfma<T, 1, 8, 4, GATE, RES, ACT>(a, ceil_div(a.M, 32), a.NTILES, stream);
         return;
     }
@@ -487,7 +644,9 @@ std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
         std::snprintf(buf, sizeof(buf), "whenet_pw_check_kernel<%s, %s, %s, %d>", t, gate, res, a.act);
     } else {
         const PwChoice ch = choose_pw(a, num_cus);
-        if (ch.kind == 1) std::snprintf(buf, sizeof(buf), "whenet_pw_kernel<%s, 1, 8, 4, %s, %s, %d>", t, gate, res, a.act);
+        if (ch.kind == 1 && use_split2(a.M, a.NTILES))
+            std::snprintf(buf, sizeof(buf), "whenet_pw_split2_kernel<%s, %s, %s, %d>", t, gate, res, a.act);
+        else if (ch.kind == 1) std::snprintf(buf, sizeof(buf), "whenet_pw_kernel<%s, 1, 8, 4, %s, %s, %d>", t, gate, res, a.act);
         else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d>", t, ch.NT, gate, res, a.act);
     }
     return buf;

@@ -344,3 +344,18 @@ def test_forwards_in_flight_are_bitwise_identical(blob, golden):
             h.set_option("inflight", 9)
         h.set_option("inflight", 1)
         assert h.forward(crops)[0].tobytes() == ref[0].tobytes()
+
+
+@pytest.mark.gpu
+def test_large_batch_gemm_path_is_bitwise_the_small_batch_path(handle):
+    """K >= 320 convs take the 2x2 register-blocked split-K kernel from 4096 rows (14x14 maps from 21
+    crops per launch, 7x7 maps from 84): same partial sums, same bits as the crops run in chunks."""
+    handle.set_option("lanes", 1)
+    try:
+        crops = np.concatenate([synth.scene_crops(40, seed=5), synth.noise_crops(56, seed=6)])     # 96 crops
+        big = handle.forward(crops, want_logits=True)
+        for i in range(0, 96, 16):
+            small = handle.forward(crops[i:i + 16], want_logits=True)
+            assert np.array_equal(small[2], big[2][i:i + 16]) and np.array_equal(small[0], big[0][i:i + 16])
+    finally:
+        handle.set_option("lanes", 3)
