@@ -105,3 +105,28 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
                 assert "whenet_oracle" not in src and "whenet_torch" not in src, os.path.join(dp, f)
+
+
+def test_header_is_valid_c(tmp_path):
+    """include/whenet_hip.h is the C ABI: it must compile as C (no C++-isms), as a C caller sees it."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "use_header.c"
+    src.write_text(
+        '#include "whenet_hip.h"\n'
+        "int probe(whenet_t* h, const uint8_t* crops, int n, float* ypr) {\n"
+        "    whenet_info_t info; whenet_launch_stat_t st; int ticket = 0; int32_t rects[4];\n"
+        "    const float box[4] = {1.f, 2.f, 30.f, 40.f};\n"
+        "    (void)st; (void)sizeof(info);\n"
+        '    if (whenet_set_option(h, "inflight", 3) != WHENET_OK) return -1;\n'
+        "    if (whenet_frame_rects(720, 1280, box, 1, rects) != WHENET_OK) return -1;\n"
+        "    if (whenet_submit_u8(h, crops, n, &ticket) != WHENET_OK) return -1;\n"
+        "    return whenet_collect(h, ticket, ypr, 0, 0);\n"
+        "}\n")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{inc}", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
