@@ -29,6 +29,7 @@ Extra objects on the line:
                 Keras path cannot run here), timed on this box's host cores, rank 0, N=1
   latency_b1    configs[1]: batch=1 fp32 single-crop latency (median / p99), N=1 only
   frame_pipeline  configs[4]: one video frame + k head boxes per submission (PCIe included), N=1 only
+  pcie_inclusive  the host-pointer forms on the same batch, H2D + D2H included (never `value`)
   serial_schedule the timed region with one forward at a time
 """
 from __future__ import annotations
@@ -161,6 +162,36 @@ def frame_leg(h):
         res[f"k{k}"] = {"sync_median_us": float(np.median(lat)), "sync_p99_us": float(np.percentile(lat, 99)),
                         "pipelined_frames_per_s": n / el, "pipelined_heads_per_s": n * k / el}
     return res
+
+
+def host_leg(h, crops):
+    """Host-pointer forms, H2D of the crops (150,528 B each) and D2H of the results included:
+    blocking whenet_forward_u8 (pageable numpy memory), and whenet_submit_u8 / whenet_collect with
+    the handle's engines (pinned staging, forwards of successive batches overlapping)."""
+    B = crops.shape[0]
+    for _ in range(5):
+        h.forward(crops)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 0.5:
+        h.forward(crops)
+        n += 1
+    blocking = n * B / (time.perf_counter() - t0)
+    pend = []
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(120):
+        if len(pend) == 3:
+            h.collect(pend.pop(0), B)
+            done += 1
+        pend.append(h.submit(crops))
+    while pend:
+        h.collect(pend.pop(0), B)
+        done += 1
+    piped = done * B / (time.perf_counter() - t0)
+    return {"batch": B, "dtype": "f16", "forward_u8_blocking_crops_s": blocking,
+            "submit_collect_3_in_flight_crops_s": piped,
+            "note": "host uint8 crops in, angles out; H2D 9.6 MB per batch of 64 over PCIe included"}
 
 
 def main():
@@ -352,6 +383,8 @@ def main():
         # configs[4]: one video frame = one submission (host BGR frame + k YOLO boxes -> pinned copy,
         # H2D, crop/resize on the device, forward of the k heads, D2H), PCIe-inclusive, f16
         out["frame_pipeline"] = frame_leg(h)
+        # PCIe-inclusive rates of the host-pointer forms on the same batch (never `value`)
+        out["pcie_inclusive"] = host_leg(h, crops)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     h.close()
