@@ -209,6 +209,12 @@ def main():
     import torch.distributed as dist
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ:               # WHENET_FORCE_DIST=1 without a launcher: a 1-rank group
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            sk.close()
+            os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "1", "0"
         dist.init_process_group("nccl", device_id=dev)
 
     from whenet_hip import _lib, synth, weights as W
