@@ -101,16 +101,26 @@ int whenet_create(const char* snapshot_path, int device_id, int dtype, whenet_t*
             g_create_error = std::string("cannot open snapshot '") + snapshot_path + "'";
             return WHENET_ENOENT;
         }
-        const std::streamsize sz = f.tellg();
-        f.seekg(0);
+        const std::streamoff sz = f.tellg();
+        // a directory or an unseekable path reports -1 (or nonsense): an I/O error, not an allocation
+        if (sz < 0 || !f.seekg(0) || uint64_t(sz) > (uint64_t(1) << 32)) {
+            g_create_error = std::string("snapshot '") + snapshot_path + "' is not a readable regular file";
+            return WHENET_EIO;
+        }
         blob.resize(size_t(sz));
-        if (sz > 0 && !f.read(blob.data(), sz)) {
+        if (sz > 0 && !f.read(blob.data(), std::streamsize(sz))) {
             g_create_error = std::string("cannot read snapshot '") + snapshot_path + "'";
             return WHENET_EIO;
         }
     } catch (const std::bad_alloc&) {
         g_create_error = "out of host memory";
         return WHENET_ENOMEM;
+    } catch (const std::exception& e) {
+        g_create_error = std::string("cannot read snapshot '") + snapshot_path + "': " + e.what();
+        return WHENET_EIO;
+    } catch (...) {
+        g_create_error = std::string("cannot read snapshot '") + snapshot_path + "'";
+        return WHENET_EIO;
     }
     return create_impl(blob.data(), blob.size(), device_id, dtype, out);
 }
@@ -178,6 +188,10 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
 
 int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits) {
     return guarded(h, [&](whenet::Engine& e) { e.forward_host(crops, n, ypr, argmax, logits); });
+}
+
+int whenet_forward_f32(whenet_t* h, const float* image, int n, float* ypr, int32_t* argmax, float* logits) {
+    return guarded(h, [&](whenet::Engine& e) { e.forward_host_f32(image, n, ypr, argmax, logits); });
 }
 
 int whenet_forward_u8_device(whenet_t* h, const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax,

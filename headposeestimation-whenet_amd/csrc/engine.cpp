@@ -167,7 +167,7 @@ Engine::~Engine() {
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, in_u8_, o_ypr_, o_amax_, o_logits_};
+    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
@@ -483,11 +483,12 @@ TailArgs Engine::tail_args(const View& v, const void* x_in, int n, int nblk, flo
 }
 
 void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
-                             hipStream_t s, LaunchRecorder* rec) {
+                             hipStream_t s, LaunchRecorder* rec, const float* d_in_f32) {
     Rec R{rec, s, repeat_};
     const double es = double(esz());
     {
         StemArgs a{d_in, v.x0, d_stem_w_, d_stem_b_, d_lut_, n};
+        a.in_f32 = d_in_f32;
         R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
           [&] { launch_stem(a, dtype_, s); });
     }
@@ -661,6 +662,32 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
     const size_t N = size_t(n);
     WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
     run_forward(in_u8_, n, o_ypr_, o_amax_, o_logits_, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    if (logits)
+        WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// Model.predict on the NORMALISED float32 image (whenet.py:27) + decode: the path for real-valued
+// crops (whenet.py:25 divides whatever dtype it is given by 255), which the byte LUT cannot serve.
+// Eager launches (no graph): a compatibility path, not the one bench.py times.
+void Engine::forward_host_f32(const float* x, int n, float* ypr, int32_t* argmax, float* logits) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(x != nullptr && ypr != nullptr, WHENET_EINVAL, "image and ypr must not be NULL");
+    ensure_capacity(n);
+    const size_t N = size_t(n);
+    if (n > in_f32_cap_) {
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+        if (in_f32_) (void)hipFree(in_f32_);
+        in_f32_ = nullptr;
+        in_f32_cap_ = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&in_f32_), N * IN_BYTES * sizeof(float));
+        if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("float input buffer: ") + hipGetErrorString(e));
+        in_f32_cap_ = n;
+    }
+    WHENET_HIP_CHECK(hipMemcpyAsync(in_f32_, x, N * IN_BYTES * sizeof(float), hipMemcpyHostToDevice, stream_));
+    enqueue_forward(view(0), nullptr, n, o_ypr_, o_amax_, o_logits_, stream_, nullptr, in_f32_);
     WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     if (logits)

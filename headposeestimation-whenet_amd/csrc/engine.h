@@ -68,6 +68,7 @@ class Engine {
     void get_info(whenet_info_t* out) const;
 
     void forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits);
+    void forward_host_f32(const float* x, int n, float* ypr, int32_t* argmax, float* logits);
     void forward_device(const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax, float* d_logits,
                         hipStream_t stream);
     void sync();
@@ -125,7 +126,7 @@ class Engine {
     View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
     void enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
-                         hipStream_t s, LaunchRecorder* rec);
+                         hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr);
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
                        LaunchRecorder* rec);
     TailArgs tail_args(const View& v, const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr,
@@ -171,6 +172,8 @@ class Engine {
     void *x0_ = nullptr, *x1_ = nullptr, *e_ = nullptr, *d_ = nullptr, *hc_ = nullptr;
     float *partial_ = nullptr, *gate_ = nullptr;
     uint8_t* in_u8_ = nullptr;
+    float* in_f32_ = nullptr;       // normalised float32 input of forward_host_f32 (grown on demand)
+    int in_f32_cap_ = 0;
     float* o_ypr_ = nullptr;
     int32_t* o_amax_ = nullptr;
     float* o_logits_ = nullptr;

@@ -18,6 +18,7 @@ struct StemArgs {
     const float* bias;     // [32]
     const float* lut;      // [3][256]
     int n;
+    const float* in_f32 = nullptr;   // != NULL: the normalised float32 image [n,224,224,3] instead of `in`
 };
 void launch_stem(const StemArgs& a, int dtype, hipStream_t stream);
 

@@ -119,18 +119,25 @@ std::map<std::string, RawTensor> parse_snapshot(const void* blob, size_t nbytes)
         uint8_t nd = r.get<uint8_t>();
         WHENET_REQUIRE(dt == 0 && nd >= 1 && nd <= 4, WHENET_EFORMAT, "snapshot: " + name + ": unsupported dtype/rank");
         RawTensor t;
-        size_t count = 1;
+        uint64_t count = 1;
+        const uint64_t max_count = uint64_t(nbytes) / 4;      // no tensor can hold more elements than the file has
         for (int d = 0; d < nd; ++d) {
             uint32_t x = r.get<uint32_t>();
             t.dims.push_back(x);
+            // overflow-safe product: bail out as soon as it exceeds what the blob could hold
+            WHENET_REQUIRE(x == 0 || count <= max_count / x, WHENET_EFORMAT,
+                           "snapshot: " + name + ": dimensions exceed the file size");
             count *= x;
         }
         uint64_t off = r.get<uint64_t>();
         uint64_t nb = r.get<uint64_t>();
-        WHENET_REQUIRE(nb == count * 4 && data_off + off + nb <= nbytes && ((data_off + off) % 4) == 0,
+        // every comparison is written so that no intermediate sum can wrap (a crafted offset near
+        // 2^64 must not pass): data_off <= nbytes was checked above
+        const uint64_t room = uint64_t(nbytes) - data_off;
+        WHENET_REQUIRE(nb == count * 4 && off <= room && nb <= room - off && ((data_off + off) % 4) == 0,
                        WHENET_EFORMAT, "snapshot: " + name + ": payload out of bounds");
         t.data = reinterpret_cast<const float*>(p + data_off + off);
-        t.count = count;
+        t.count = size_t(count);
         for (size_t j = 0; j < count; ++j)
             WHENET_REQUIRE(std::isfinite(t.data[j]), WHENET_EFORMAT, "snapshot: " + name + ": non-finite value");
         out.emplace(std::move(name), std::move(t));

@@ -24,7 +24,9 @@ constexpr int IN_ROWS = 2 * ROWS_PER_BLOCK + 1;      // 5
 constexpr int ROW_FLOATS = 225 * 3 + 1;              // 675 (+1 pad): column 224 is the zero pad
 constexpr int ROW_DWORDS = IMG * 3 / 4;              // 168
 
-template <typename T>
+// INF32 = true: the input is the already NORMALISED float32 image [n,224,224,3] that the reference
+// hands to Model.predict (whenet.py:27) -- the path for real-valued crops, which have no byte LUT.
+template <typename T, bool INF32>
 __global__ __launch_bounds__(256) void whenet_stem_kernel(const uint8_t* __restrict__ in, T* __restrict__ out,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
@@ -36,18 +38,23 @@ __global__ __launch_bounds__(256) void whenet_stem_kernel(const uint8_t* __restr
     const int oy0 = blockIdx.x * ROWS_PER_BLOCK;
     const int b = blockIdx.y;
 
-    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = lut[i];
+    if constexpr (!INF32)
+        for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = lut[i];
     // zero pad column (x = 224) of every staged row
     if (tid < IN_ROWS * 4) s_img[(tid >> 2) * ROW_FLOATS + 672 + (tid & 3)] = 0.0f;
     __syncthreads();
 
     const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in + size_t(b) * IMG * IMG * 3);
+    const float4v* inf = reinterpret_cast<const float4v*>(reinterpret_cast<const float*>(in) + size_t(b) * IMG * IMG * 3);
     for (int d = tid; d < IN_ROWS * ROW_DWORDS; d += 256) {
         const int r = d / ROW_DWORDS;
         const int j = d - r * ROW_DWORDS;
         const int iy = 2 * oy0 + r;
         float* dst = &s_img[r * ROW_FLOATS + 4 * j];
-        if (iy < IMG) {
+        if (INF32 && iy < IMG) {
+            const float4v v = inf[iy * ROW_DWORDS + j];
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        } else if (iy < IMG) {
             const uint32_t v = in32[iy * ROW_DWORDS + j];
             int ch = (4 * j) % 3;
 #pragma unroll
@@ -98,17 +105,25 @@ __global__ __launch_bounds__(256) void whenet_stem_kernel(const uint8_t* __restr
 
 void launch_stem(const StemArgs& a, int dtype, hipStream_t stream) {
     dim3 grid(STEM_HW / ROWS_PER_BLOCK, a.n);
-    if (dtype == WHENET_F16)
-        hipLaunchKernelGGL(whenet_stem_kernel<half_t>, grid, dim3(256), 0, stream, a.in, static_cast<half_t*>(a.out),
-                           a.w, a.bias, a.lut);
+    if (a.in_f32 != nullptr) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(a.in_f32);
+        if (dtype == WHENET_F16)
+            hipLaunchKernelGGL((whenet_stem_kernel<half_t, true>), grid, dim3(256), 0, stream, src,
+                               static_cast<half_t*>(a.out), a.w, a.bias, a.lut);
+        else
+            hipLaunchKernelGGL((whenet_stem_kernel<float, true>), grid, dim3(256), 0, stream, src,
+                               static_cast<float*>(a.out), a.w, a.bias, a.lut);
+    } else if (dtype == WHENET_F16)
+        hipLaunchKernelGGL((whenet_stem_kernel<half_t, false>), grid, dim3(256), 0, stream, a.in,
+                           static_cast<half_t*>(a.out), a.w, a.bias, a.lut);
     else
-        hipLaunchKernelGGL(whenet_stem_kernel<float>, grid, dim3(256), 0, stream, a.in, static_cast<float*>(a.out),
-                           a.w, a.bias, a.lut);
+        hipLaunchKernelGGL((whenet_stem_kernel<float, false>), grid, dim3(256), 0, stream, a.in,
+                           static_cast<float*>(a.out), a.w, a.bias, a.lut);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
 const char* kernel_name_stem(int dtype) {
-    return dtype == WHENET_F16 ? "whenet_stem_kernel<_Float16>" : "whenet_stem_kernel<float>";
+    return dtype == WHENET_F16 ? "whenet_stem_kernel<_Float16, false>" : "whenet_stem_kernel<float, false>";
 }
 
 }  // namespace whenet

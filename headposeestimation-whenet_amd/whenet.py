@@ -37,20 +37,19 @@ _DTYPES = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32,
            "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16}
 
 
-def _as_uint8_crops(img) -> np.ndarray:
-    """Validate like Keras would at Model.predict (ValueError on wrong rank/shape) and return
-    a contiguous uint8 array.  The reference divides by 255 whatever the dtype
-    (whenet.py:25); integer-valued arrays in [0,255] of any dtype are therefore accepted."""
-    a = np.asarray(img)
+_as_uint8_crops = _lib.as_uint8_crops
+
+
+def _is_byte_valued(a: np.ndarray) -> bool:
+    if a.dtype == np.uint8:
+        return True
+    return bool(a.size == 0 or (a.min() >= 0 and a.max() <= 255 and np.all(a == np.rint(a))))
+
+
+def _check_shape(a: np.ndarray) -> None:
     if a.ndim != 4 or tuple(a.shape[1:]) != (spec.IMG, spec.IMG, 3):
         raise ValueError(f"Error when checking input: expected input to have shape "
                          f"(None, 224, 224, 3) but got array with shape {a.shape}")
-    if a.dtype != np.uint8:
-        if a.size and (a.min() < 0 or a.max() > 255 or not np.all(a == np.rint(a))):
-            raise ValueError("get_angle expects 8-bit RGB crops (integer values 0..255), as produced by "
-                             "cv2.resize on an image (demo.py:11)")
-        a = a.astype(np.uint8)
-    return np.ascontiguousarray(a)
 
 
 class _Model:
@@ -88,24 +87,14 @@ class _Model:
         print("_" * 78)
 
     def predict(self, x, batch_size=8, **_):
-        """Model.predict(img, batch_size=8) (whenet.py:27).  ``x`` is the *normalised* float
-        image the reference passes; the HIP path consumes bytes (it normalises through a LUT),
-        so ``x`` is mapped back to the uint8 crop it came from -- exactly invertible for
-        anything produced by whenet.py:23-26 -- and rejected otherwise."""
+        """Model.predict(img, batch_size=8) (whenet.py:27): ``x`` is the *normalised* image the
+        reference passes; Keras casts it to float32 and returns the three logit arrays.
+        ``batch_size`` only caps Keras' internal chunking (numerically irrelevant)."""
         x = np.asarray(x)
-        if x.ndim != 4 or tuple(x.shape[1:]) != (spec.IMG, spec.IMG, 3):
-            raise ValueError(f"Error when checking input: expected input to have shape "
-                             f"(None, 224, 224, 3) but got array with shape {x.shape}")
-        mean = np.array(spec.MEAN)
-        std = np.array(spec.STD)
-        u8f = np.rint((x.astype(np.float64) * std + mean) * 255.0)
-        if u8f.min() < 0 or u8f.max() > 255:
-            raise ValueError("predict(): input is not a normalised 8-bit image")
-        u8 = u8f.astype(np.uint8)
-        back = ((u8 / 255 - mean) / std)
-        if not np.allclose(back, x, rtol=0, atol=1e-5):
-            raise ValueError("predict(): input is not a normalised 8-bit image (whenet.py:23-26)")
-        _, _, lg = self._outer._forward(u8)
+        _check_shape(x)
+        if x.shape[0] == 0:
+            return [np.empty((0, 120), np.float32), np.empty((0, 66), np.float32), np.empty((0, 66), np.float32)]
+        _, _, lg = self._outer._forward_f32(np.ascontiguousarray(x, dtype=np.float32))
         return [lg[:, :120].copy(), lg[:, 120:186].copy(), lg[:, 186:].copy()]
 
 
@@ -142,13 +131,32 @@ class WHENet:
         self.last_logits, self.last_argmax = lg, am
         return ypr, am, lg
 
+    def _forward_f32(self, x: np.ndarray):
+        ypr, am, lg = self._handle.forward_f32(x, want_logits=True)
+        self.last_logits, self.last_argmax = lg, am
+        return ypr, am, lg
+
     def get_angle(self, img):
-        """whenet.py:22-34.  img: [N,224,224,3] RGB uint8 -> (yaw, pitch, roll), float32 (N,)."""
-        u8 = _as_uint8_crops(img)
-        if u8.shape[0] == 0:
+        """whenet.py:22-34.  img: [N,224,224,3] RGB -> (yaw, pitch, roll), float32 (N,).
+
+        8-bit crops (uint8, or any numeric dtype holding integers 0..255 -- what cv2.resize of an
+        image gives, demo.py:11) go to the device as bytes and are normalised there through a LUT that
+        is the exact image of whenet.py:23-26.  Anything else numeric is handled as the reference
+        handles it: ``img/255`` and ``(img-mean)/std`` in float64 (whenet.py:23-26), cast to float32
+        as Keras does at Model.predict (whenet.py:27), then the same network."""
+        a = np.asarray(img)
+        _check_shape(a)
+        if a.dtype == object or not (np.issubdtype(a.dtype, np.number) or a.dtype == np.bool_):
+            raise ValueError(f"get_angle: crops must be numeric, got dtype {a.dtype}")
+        if a.shape[0] == 0:
             e = np.empty((0,), np.float32)
             return e, e.copy(), e.copy()
-        ypr, _, _ = self._forward(u8)
+        if _is_byte_valued(a):
+            ypr, _, _ = self._forward(np.ascontiguousarray(a.astype(np.uint8, copy=False)))
+        else:
+            x = a / 255                                                   # whenet.py:25
+            x = (x - list(spec.MEAN)) / list(spec.STD)                    # whenet.py:26
+            ypr, _, _ = self._forward_f32(np.ascontiguousarray(x, dtype=np.float32))
         return ypr[:, 0].copy(), ypr[:, 1].copy(), ypr[:, 2].copy()
 
     predict = get_angle

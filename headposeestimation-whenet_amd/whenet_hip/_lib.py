@@ -42,6 +42,7 @@ _PROTOS = {
     "whenet_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "whenet_set_option": (C.c_int, [_P, C.c_char_p, C.c_long]),
     "whenet_forward_u8": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "whenet_forward_f32": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "whenet_forward_u8_device": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "whenet_sync": (C.c_int, [_P]),
     "whenet_submit_u8": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
@@ -87,6 +88,25 @@ def load() -> C.CDLL:
 
 
 RGB, BGR = 0, 1
+
+
+def as_uint8_crops(img) -> np.ndarray:
+    """Validate like Keras would at Model.predict (ValueError on wrong rank/shape) and return a
+    contiguous uint8 array.  The reference divides by 255 whatever the dtype
+    (/root/reference/whenet.py:25); integer-valued arrays in [0,255] of any dtype are therefore
+    accepted here.  (Real-valued crops take WHENet.get_angle's float path instead.)"""
+    a = np.asarray(img)
+    if a.ndim != 4 or tuple(a.shape[1:]) != (224, 224, 3):
+        raise ValueError(f"Error when checking input: expected input to have shape "
+                         f"(None, 224, 224, 3) but got array with shape {a.shape}")
+    if a.dtype != np.uint8:
+        if a.dtype == object or not np.issubdtype(a.dtype, np.number):
+            raise ValueError(f"crops must be numeric, got dtype {a.dtype}")
+        if a.size and (a.min() < 0 or a.max() > 255 or not np.all(a == np.rint(a))):
+            raise ValueError("not 8-bit RGB crops (integer values 0..255), as produced by cv2.resize on an "
+                             "image (demo.py:11)")
+        a = a.astype(np.uint8)
+    return np.ascontiguousarray(a)
 
 
 def _frame_u8(frame) -> np.ndarray:
@@ -171,11 +191,32 @@ class Handle:
 
     # ---- hot path ---------------------------------------------------------------------
     def forward(self, crops: np.ndarray, want_logits: bool = True):
+        # the C side reads n*150,528 bytes from this pointer: never hand it anything else
+        if not (isinstance(crops, np.ndarray) and crops.dtype == np.uint8 and crops.ndim == 4
+                and crops.shape[1:] == (224, 224, 3) and crops.flags.c_contiguous):
+            raise ValueError("Handle.forward needs a C-contiguous uint8 array [n,224,224,3] "
+                             f"(got {getattr(crops, 'dtype', type(crops))} {getattr(crops, 'shape', '')}); "
+                             "use whenet_hip._lib.as_uint8_crops()")
         n = crops.shape[0]
+        if n == 0:
+            return (np.empty((0, 3), np.float32), np.empty((0, 3), np.int32),
+                    np.empty((0, 252), np.float32) if want_logits else None)
         ypr = np.empty((n, 3), np.float32)
         am = np.empty((n, 3), np.int32)
         lg = np.empty((n, 252), np.float32) if want_logits else None
         self._check(self._lib.whenet_forward_u8(self._h, _ptr(crops), n, _ptr(ypr), _ptr(am), _ptr(lg)))
+        return ypr, am, lg
+
+    def forward_f32(self, x: np.ndarray, want_logits: bool = True):
+        """x: the NORMALISED float32 image [n,224,224,3] (what whenet.py:27 feeds Model.predict)."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.ndim == 4
+                and x.shape[1:] == (224, 224, 3) and x.flags.c_contiguous and x.shape[0] >= 1):
+            raise ValueError("Handle.forward_f32 needs a C-contiguous float32 array [n>=1,224,224,3]")
+        n = x.shape[0]
+        ypr = np.empty((n, 3), np.float32)
+        am = np.empty((n, 3), np.int32)
+        lg = np.empty((n, 252), np.float32) if want_logits else None
+        self._check(self._lib.whenet_forward_f32(self._h, _ptr(x), n, _ptr(ypr), _ptr(am), _ptr(lg)))
         return ypr, am, lg
 
     def forward_device(self, d_crops: int, n: int, d_ypr: int, d_argmax: int = 0, d_logits: int = 0, stream: int = 0):
@@ -186,6 +227,9 @@ class Handle:
         self._check(self._lib.whenet_sync(self._h))
 
     def submit(self, crops: np.ndarray) -> int:
+        if not (isinstance(crops, np.ndarray) and crops.dtype == np.uint8 and crops.ndim == 4
+                and crops.shape[1:] == (224, 224, 3) and crops.flags.c_contiguous and crops.shape[0] >= 1):
+            raise ValueError("Handle.submit needs a C-contiguous uint8 array [n>=1,224,224,3]")
         t = C.c_int(-1)
         self._check(self._lib.whenet_submit_u8(self._h, _ptr(crops), crops.shape[0], C.byref(t)))
         return t.value

@@ -162,23 +162,41 @@ def convert(path: str) -> Dict[str, np.ndarray]:
     return convert_layers(read_layers(path))
 
 
-def load_as_packed(path: str) -> bytes:
-    """Keras .h5 -> WHNPACK1 bytes, cached next to the snapshot as <path>.whnp when writable."""
+def load_as_packed(path: str, cache: bool | None = None) -> bytes:
+    """Keras .h5 -> WHNPACK1 bytes.
+
+    Caching is OPT-IN (``cache=True`` or ``WHENET_H5_CACHE=1``): the converted snapshot is then kept
+    next to the file as ``<path>.whnp`` together with ``<path>.whnp.sha256`` = SHA-256 of the HDF5
+    file it was converted from; the cache is used only while that digest matches the file's current
+    content (a replaced WHENet.h5 -- whatever its mtime -- or a stray .whnp is never trusted)."""
+    import hashlib
     from . import weights as W
-    cache = path + ".whnp"
-    if os.path.exists(cache) and os.path.getmtime(cache) >= os.path.getmtime(path) and W.is_packed(cache):
-        with open(cache, "rb") as f:
-            return f.read()
+    if cache is None:
+        cache = os.environ.get("WHENET_H5_CACHE", "0") not in ("", "0")
     with open(path, "rb") as f:
-        magic = f.read(8)
-    if magic != b"\x89HDF\r\n\x1a\n":
+        raw = f.read()
+    if raw[:8] != b"\x89HDF\r\n\x1a\n":
         raise ValueError(f"{path}: neither a WHNPACK1 snapshot nor an HDF5 file")
+    digest = hashlib.sha256(raw).hexdigest()
+    cpath, kpath = path + ".whnp", path + ".whnp.sha256"
+    if cache and os.path.exists(cpath) and os.path.exists(kpath):
+        try:
+            with open(kpath) as f:
+                key = f.read().strip()
+            if key == digest and W.is_packed(cpath):
+                with open(cpath, "rb") as f:
+                    return f.read()
+        except OSError:
+            pass
     blob = W.pack(convert(path))
-    try:
-        with open(cache, "wb") as f:
-            f.write(blob)
-    except OSError:
-        pass
+    if cache:
+        try:
+            with open(cpath, "wb") as f:
+                f.write(blob)
+            with open(kpath, "w") as f:
+                f.write(digest + "\n")
+        except OSError:
+            pass
     return blob
 
 

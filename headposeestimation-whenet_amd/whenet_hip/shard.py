@@ -95,17 +95,25 @@ class ShardedWHENet:
         """Run this rank's shard.  With global_batch=True `crops` is the whole batch (every
         rank passes the same array) and the shard is sliced here; otherwise it already is
         this rank's shard."""
+        from ._lib import as_uint8_crops
+        crops = np.asarray(crops)
+        if crops.ndim != 4 or tuple(crops.shape[1:]) != (224, 224, 3):
+            raise ValueError(f"Error when checking input: expected input to have shape "
+                             f"(None, 224, 224, 3) but got array with shape {crops.shape}")
         if global_batch:
             lo, hi = self.bounds(crops.shape[0])
             crops = crops[lo:hi]
         if crops.shape[0] == 0:
             return np.empty((0, 3), np.float32), np.empty((0, 3), np.int32)
-        return self._forward(np.ascontiguousarray(crops))
+        # same validation / dtype handling as WHENet.get_angle (whenet.py:22-27): the C side reads
+        # raw bytes, so nothing but a contiguous uint8 [m,224,224,3] array may reach it
+        return self._forward(as_uint8_crops(crops))
 
     def get_angle(self, crops: np.ndarray):
         """Whole-batch result on every rank: shard, run, all_gather.  Returns (yaw, pitch, roll)
         like whenet.py:22-34, each float32 (N,), in the original crop order."""
-        n = crops.shape[0]
+        crops = np.asarray(crops)
+        n = crops.shape[0] if crops.ndim == 4 else 0
         ypr, am = self.forward_local(crops, global_batch=True)
         if self.world == 1:
             return ypr[:, 0].copy(), ypr[:, 1].copy(), ypr[:, 2].copy()

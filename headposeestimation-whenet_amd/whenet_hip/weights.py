@@ -233,12 +233,12 @@ def apply_calibration(w: Dict[str, np.ndarray], calib: Dict[str, np.ndarray],
 
 def synthetic(seed: int = 1234, calib_path: Optional[str] = None) -> Dict[str, np.ndarray]:
     """The synthetic snapshot every test / bench number in this repo is quoted on:
-    ``synthetic_raw(seed)`` + the committed calibration fixture
-    (tests/golden/calib_seed1234.npz, produced by tests/golden/make_golden.py)."""
+    ``synthetic_raw(seed)`` + the calibration data shipped inside the package
+    (whenet_hip/data/calib_seed1234.npz, produced by tests/golden/make_golden.py)."""
     import os
     if calib_path is None:
         here = os.path.dirname(os.path.abspath(__file__))
-        calib_path = os.path.join(here, "..", "..", "tests", "golden", f"calib_seed{seed}.npz")
+        calib_path = os.path.join(here, "data", f"calib_seed{seed}.npz")
     with np.load(calib_path) as z:
         calib = {k: z[k] for k in z.files}
     return apply_calibration(synthetic_raw(seed), calib, seed)

@@ -115,6 +115,14 @@ WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
 WHENET_API int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n,
                       float* ypr, int32_t* argmax, float* logits);
 
+/* The same path for REAL-VALUED input: `image` is the normalised float32 image [n,224,224,3] that
+ * the reference hands to Model.predict (whenet.py:27) -- i.e. (img/255 - mean)/std computed by
+ * the caller as whenet.py:23-26 does (float64, then cast).  whenet.py:25 divides any numeric array
+ * by 255, so crops that are not 8-bit integers (no byte LUT applies) take this entry point; the
+ * drop-in get_angle routes them here.  Host pointers, blocking, eager launches. */
+WHENET_API int whenet_forward_f32(whenet_t* h, const float* image, int n,
+                       float* ypr, int32_t* argmax, float* logits);
+
 /* Device-pointer form: all pointers are device memory on the handle's GPU; the work is
  * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream, or with option "inflight"
  * > 1 the next of the handle's engines) and the call returns without waiting.  This is the form

@@ -16,23 +16,18 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 """
 from __future__ import annotations
 
-import os
-import sys
 from typing import Dict, List, Tuple
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-_PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "headposeestimation-whenet_amd")
-if _PKG not in sys.path:
-    sys.path.insert(0, _PKG)
-from whenet_hip import spec  # noqa: E402
+from . import b0_spec as G       # the oracle's own geometry (nothing is imported from the product package)
 
 
 def _same(x: torch.Tensor, k: int, s: int) -> torch.Tensor:
-    _, pb, pa = spec.same_pad(x.shape[2], k, s)
-    _, qb, qa = spec.same_pad(x.shape[3], k, s)
+    _, pb, pa = G.tf_same(x.shape[2], k, s)
+    _, qb, qa = G.tf_same(x.shape[3], k, s)
     if pb or pa or qb or qa:
         x = F.pad(x, (qb, qa, pb, pa))
     return x
@@ -59,7 +54,7 @@ class TorchWHENet:
     def _bn(self, x: torch.Tensor, prefix: str) -> torch.Tensor:
         p = self.p
         return F.batch_norm(x, p[f"{prefix}/mean"], p[f"{prefix}/var"], p[f"{prefix}/gamma"],
-                            p[f"{prefix}/beta"], training=False, eps=spec.BN_EPS)
+                            p[f"{prefix}/beta"], training=False, eps=G.BN_EPSILON)
 
     @torch.no_grad()
     def logits(self, x_nhwc_f32: np.ndarray) -> List[np.ndarray]:
@@ -67,19 +62,19 @@ class TorchWHENet:
         p = self.p
         x = torch.from_numpy(np.ascontiguousarray(x_nhwc_f32)).to(self.dtype).permute(0, 3, 1, 2).contiguous()
         x = F.silu(self._bn(F.conv2d(_same(x, 3, 2), p["stem/conv/kernel"], stride=2), "stem/bn"))
-        for b in spec.blocks():
-            q = f"b{b.index}"
+        for b in G.mbconv_blocks():
+            q = f"b{b.number}"
             inp = x
-            if b.has_expand:
+            if b.expands:
                 x = F.silu(self._bn(F.conv2d(x, p[f"{q}/expand/kernel"]), f"{q}/expand_bn"))
-            x = F.conv2d(_same(x, b.k, b.s), p[f"{q}/dw/kernel"], stride=b.s, groups=b.cexp)
+            x = F.conv2d(_same(x, b.kernel, b.stride), p[f"{q}/dw/kernel"], stride=b.stride, groups=b.filters_mid)
             x = F.silu(self._bn(x, f"{q}/dw_bn"))
             sq = x.mean(dim=(2, 3), keepdim=True)
             r = F.silu(F.conv2d(sq, p[f"{q}/se_reduce/kernel"], p[f"{q}/se_reduce/bias"]))
             g = torch.sigmoid(F.conv2d(r, p[f"{q}/se_expand/kernel"], p[f"{q}/se_expand/bias"]))
             x = x * g
             x = self._bn(F.conv2d(x, p[f"{q}/project/kernel"]), f"{q}/project_bn")
-            if b.has_skip:
+            if b.identity_skip:
                 x = x + inp
         x = F.silu(self._bn(F.conv2d(x, p["head/conv/kernel"]), "head/bn"))
         f = x.mean(dim=(2, 3))

@@ -10,9 +10,11 @@ Outputs
                         but decoded and resized with PIL (bilinear), because cv2 is not
                         installable here; parity is defined on identical uint8 crops, so
                         both the oracle and the HIP path consume these bytes.
-  calib_seed1234.npz    BN moving statistics + head calibration of the seeded synthetic
-                        snapshot (whenet_hip/weights.py::synthetic) -- the trained
-                        WHENet.h5 is absent from the reference (.MISSING_LARGE_BLOBS:1).
+  ../../headposeestimation-whenet_amd/whenet_hip/data/calib_seed1234.npz
+                        BN moving statistics + head calibration of the seeded synthetic
+                        snapshot (whenet_hip/weights.py::synthetic; shipped inside the package, the
+                        product never reads tests/) -- the trained WHENet.h5 is absent from the
+                        reference (.MISSING_LARGE_BLOBS:1).
   golden_crops.npy      [8,224,224,3] u8: 2 sample + 4 scene + 2 noise crops.
   golden_expected.npz   float64-oracle logits / angles / argmax / top-2 margins for those
                         crops, plus the float32 restatements' deviations (noise floor).
@@ -94,7 +96,7 @@ def main():
     cal_crops = np.concatenate([sc, synth.scene_crops(8, seed=100), synth.noise_crops(4, seed=101)])
     w = weights.synthetic_raw(SEED)
     calib = calibrate(w, cal_crops)
-    np.savez(os.path.join(HERE, f"calib_seed{SEED}.npz"), **calib)
+    np.savez(os.path.join(ROOT, "headposeestimation-whenet_amd", "whenet_hip", "data", f"calib_seed{SEED}.npz"), **calib)
 
     w = weights.synthetic(SEED)
     bb, hd = spec.param_count()

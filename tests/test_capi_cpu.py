@@ -91,9 +91,11 @@ def test_dropin_module_surface():
     with pytest.raises(ValueError):
         whenet._as_uint8_crops(np.zeros((224, 224, 3), np.uint8))
     with pytest.raises(ValueError):
-        whenet._as_uint8_crops(np.zeros((1, 224, 224, 3), np.float32) + 0.5)
+        whenet._as_uint8_crops(np.zeros((1, 224, 224, 3), np.float32) + 0.5)    # bytes path only
     ok = whenet._as_uint8_crops(np.full((2, 224, 224, 3), 7.0))
     assert ok.dtype == np.uint8 and ok.flags.c_contiguous
+    assert whenet._is_byte_valued(np.full((1, 2), 7.0)) and not whenet._is_byte_valued(np.full((1, 2), 7.5))
+    assert not whenet._is_byte_valued(np.full((1, 2), -1.0)) and not whenet._is_byte_valued(np.full((1, 2), 256))
 
 
 def test_product_never_imports_oracle():
@@ -130,3 +132,50 @@ def test_header_is_valid_c(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{inc}", str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_snapshot_table_overflow_is_rejected(weights):
+    """offsets / sizes near 2^64 and wrapping dimension products must not pass the bounds
+    check of the WHNPACK1 table (csrc/snapshot.cpp)."""
+    import struct
+    blob = bytearray(W.pack(weights))
+    # first table entry: u16 name_len, name, u8 dtype, u8 ndim, u32 dims[ndim], u64 off, u64 nbytes
+    p = 24
+    (ln,) = struct.unpack_from("<H", blob, p)
+    q = p + 2 + ln
+    nd = blob[q + 1]
+    dims_at = q + 2
+    off_at = dims_at + 4 * nd
+    good = bytes(blob)
+    # (a) offset near 2^64: data_off + off + nb wraps around
+    b = bytearray(good)
+    struct.pack_into("<Q", b, off_at, (1 << 64) - 64)
+    with pytest.raises(ValueError):
+        _lib.Handle(bytes(b))
+    # (b) dimension product wraps to the true count: dims (2^31, 2^31, 2, count/...)
+    b = bytearray(good)
+    struct.pack_into(f"<{nd}I", b, dims_at, *([0x80000000] * nd))
+    with pytest.raises(ValueError):
+        _lib.Handle(bytes(b))
+    # (c) size larger than the file
+    b = bytearray(good)
+    struct.pack_into("<Q", b, off_at + 8, 1 << 40)
+    with pytest.raises(ValueError):
+        _lib.Handle(bytes(b))
+
+
+def test_create_on_a_directory_is_an_os_error(tmp_path):
+    with pytest.raises(OSError):
+        _lib.Handle(str(tmp_path))
+
+
+def test_handle_forward_rejects_anything_but_uint8_crops():
+    """Handle.forward / the shard path must never hand the C side a buffer of the wrong size/dtype
+    (ADVICE r1): validation happens before the handle is even touched."""
+    h = _lib.Handle.__new__(_lib.Handle)          # no device needed: the checks come first
+    for bad in (np.zeros((1, 224, 224, 3), np.float32), np.zeros((1, 100, 100, 3), np.uint8),
+                np.zeros((2, 224, 224, 3), np.uint8)[:, ::2].repeat(2, axis=1)[:, :, ::-1], [[1, 2]]):
+        with pytest.raises(ValueError):
+            _lib.Handle.forward(h, bad)
+    with pytest.raises(ValueError):
+        _lib.Handle.forward_f32(h, np.zeros((1, 224, 224, 3), np.float64))

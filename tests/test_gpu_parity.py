@@ -5,8 +5,12 @@ Tolerances (stated here, per dtype):
   f32  angles <= 1e-3 deg (the north-star bar), bin argmax equal wherever the oracle's top-2
        logit margin exceeds 2e-3 (float32 round-off moves logits by ~3e-4, see
        tests/golden/golden.json noise_floor_*), per-kernel tensors <= 2e-5 * scale;
-  f16  cannot meet 1e-3 deg (10-bit mantissa through 82 conv layers): angles <= F16_DEG,
-       per-kernel tensors <= 4e-3 * scale (each kernel alone, fed oracle inputs rounded to f16).
+  f16  cannot meet 1e-3 deg (10-bit mantissa through 82 conv layers): angles <= F16_DEG (0.5;
+       0.05-0.27 measured), per-kernel tensors <= 1.5e-2 * scale (each kernel alone, fed oracle inputs
+       rounded to f16); bin argmax: asserted on EVERY golden crop -- equal, or the oracle's top-2
+       margin is below the measured logit error (the synthetic heads are 3-bin-wide Gaussian bumps:
+       neighbouring bins differ by <= 0.38, so f16 may legitimately pick the neighbour) and the
+       picked bin is the oracle's runner-up; at most F16_ARGMAX_FLIPS of the 24 may flip.
 """
 import os
 
@@ -19,7 +23,8 @@ from whenet_hip import _lib, spec, synth, weights as W
 pytestmark = pytest.mark.gpu
 
 F32_DEG = 1e-3
-F16_DEG = 1.0
+F16_DEG = 0.5
+F16_ARGMAX_FLIPS = 3
 MARGIN_F32 = 2e-3
 DTYPES = [("f32", _lib.F32), ("f16", _lib.F16)]
 
@@ -178,9 +183,22 @@ def test_end_to_end_golden(handle, golden):
         assert np.array_equal(am[safe], exp["argmax"][safe])
     else:
         assert err <= F16_DEG
-        noise = np.abs(lg - exp["logits"]).max()
-        safe = exp["margins"] > 4 * noise
-        assert np.array_equal(am[safe], exp["argmax"][safe])
+        # bin argmax on every golden crop and head (no vacuous mask): either equal, or a flip to the
+        # oracle's runner-up bin whose margin is below this run's logit error -- and only a few
+        noise = float(np.abs(lg - exp["logits"]).max())
+        flips = np.argwhere(am != exp["argmax"])
+        print(f"[f16] argmax flips {len(flips)}/{am.size}; logit noise {noise:.3f}; "
+              f"smallest oracle top-2 margin {exp['margins'].min():.3f}")
+        assert len(flips) <= F16_ARGMAX_FLIPS, flips
+        lo = {0: 0, 1: 120, 2: 186}
+        nb = {0: 120, 1: 66, 2: 66}
+        for i, h in flips:
+            ref = exp["logits"][i, lo[h]:lo[h] + nb[h]]
+            runner_up = int(np.argsort(ref)[-2])
+            assert exp["margins"][i, h] <= 2 * noise, (i, h, exp["margins"][i, h], noise)
+            assert am[i, h] == runner_up, (i, h, am[i, h], runner_up)
+        big = exp["margins"] > 2 * noise
+        assert np.array_equal(am[big], exp["argmax"][big])
 
 
 def test_mfma_against_scalar_check_kernels(handle, golden):
@@ -218,8 +236,8 @@ def test_batch_invariance_and_permutation(handle, golden):
         try:
             y3, a3, l3 = handle.forward(crops)
         finally:
-            handle.set_option("lanes", 4)
-            handle.set_option("min_lane_crops", 8)
+            handle.set_option("lanes", 3)              # the documented defaults (include/whenet_hip.h)
+            handle.set_option("min_lane_crops", 16)
         assert np.array_equal(l3, lg) and np.array_equal(y3, ypr) and np.array_equal(a3, am)
 
 
@@ -305,6 +323,120 @@ def test_dropin_class_on_gpu(blob, golden, capsys):
     y2, _, _ = m.get_angle(c2)
     assert np.array_equal(y2, yaw) and np.array_equal(c2, crop.astype(np.float64))
     m.close()
+
+
+def test_real_valued_crops_follow_the_reference_arithmetic(blob, weights, golden):
+    """whenet.py:25 divides ANY numeric array by 255 (float64), whenet.py:26 normalises, Keras casts
+    to float32: non-integer crops take whenet_forward_f32 (no byte LUT) and must match the oracle fed
+    the same float image; byte-valued crops through that path equal the LUT path to f32 round-off;
+    Model.predict accepts any normalised float image."""
+    from whenet import WHENet
+    m = WHENet(blob)
+    crops = golden["crops"][:3]
+    soft = crops.astype(np.float64) * 0.7 + 11.3 + np.random.default_rng(2).uniform(0, 1, crops.shape)   # not integers
+    y, p, r = m.get_angle(soft)
+    x = ((soft / 255) - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]
+    lg_ref = O.heads(O.backbone(x.astype(np.float32).astype(np.float64), weights), weights)
+    yr, pr, rr = O.decode(lg_ref)
+    assert np.abs(np.stack([y, p, r], 1) - np.stack([yr, pr, rr], 1)).max() <= F32_DEG
+    assert np.abs(m.last_logits - lg_ref).max() < 2e-3
+    # the float path on byte-valued input == the LUT path (same float32 network input)
+    yb, pb, rb = m.get_angle(crops)
+    lut_logits = m.last_logits.copy()
+    xb = ((crops / 255) - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]
+    ly, lp, lr = m.model.predict(xb)
+    assert np.array_equal(np.concatenate([ly, lp, lr], 1), lut_logits)
+    # Model.predict on an arbitrary float image (not the image of any byte crop)
+    ly, lp, lr = m.model.predict(x + 0.01)
+    ref2 = O.heads(O.backbone((x + 0.01).astype(np.float32).astype(np.float64), weights), weights)
+    assert np.abs(np.concatenate([ly, lp, lr], 1) - ref2).max() < 2e-3
+    with pytest.raises(ValueError):
+        m.get_angle(np.array([["a"]], dtype=object).reshape(1, 1, 1, 1))
+    m.close()
+
+
+def test_hip_path_against_huggingface_fixture(handle, weights, golden):
+    """Pin to a third-party implementation on the GPU box too: the committed 7x7x1280 features that
+    HuggingFace transformers' EfficientNet computed from the same snapshot
+    (tests/golden/hf_features.npz) -> GAP + Dense in numpy float64 -> logits; the HIP path's logits
+    for those crops must match them (and so must the oracle's)."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "hf_features.npz"))
+    crops = golden["crops"][fx["crop_index"]]
+    lg_hf = O.heads(fx["features"].astype(np.float64), weights)
+    assert np.abs(lg_hf - golden["expected"]["logits"][fx["crop_index"]]).max() < 1e-4      # oracle == HF
+    ypr, am, lg = handle.forward(crops)
+    y, p, r = O.decode(lg_hf)
+    err = np.abs(ypr - np.stack([y, p, r], 1)).max()
+    assert err <= (F32_DEG if handle.name == "f32" else F16_DEG), err
+    if handle.name == "f32":
+        assert np.abs(lg - lg_hf).max() < 2e-3
+        assert np.array_equal(am, O.argmax_bins(lg_hf))
+
+
+def test_keras_h5_snapshot_on_the_gpu(weights, golden, tmp_path):
+    """whenet.py:15-16 / demo.py:20: WHENet('WHENet.h5').  The file is written in the Keras-2.1.6
+    HDF5 layout by the h5py helper interpreter -- with the three Dense heads stored in another order
+    than they were created (name matching) and layer numbering as if the model was built second in a
+    session -- loaded through the drop-in constructor, and must reproduce the golden angles."""
+    from whenet import WHENet
+    from whenet_hip import keras_h5
+    from tests.test_keras_h5 import shuffled_heads
+    if not os.path.exists(keras_h5.HELPER):
+        try:
+            import h5py  # noqa: F401
+        except ImportError:
+            pytest.skip("no interpreter with h5py on this box")
+    h5 = str(tmp_path / "WHENet.h5")
+    keras_h5.write_keras_h5(h5, shuffled_heads(keras_h5.to_keras_layers(weights, offset=82)))
+    m = WHENet(h5)
+    y, p, r = m.get_angle(golden["crops"])
+    assert np.abs(np.stack([y, p, r], 1) - golden["expected"]["angles"]).max() <= F32_DEG
+    assert np.array_equal(m.last_argmax, golden["expected"]["argmax"])
+    m.close()
+    with pytest.raises(OSError):
+        WHENet(str(tmp_path / "missing.h5"))
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(b"not hdf5 at all")
+    with pytest.raises(ValueError):
+        WHENet(str(junk))
+
+
+def test_sharded_whenet_over_rccl_one_rank(blob, golden):
+    """ShardedWHENet's REAL forward branch (libwhenet_hip handle on this rank's GPU, snapshot
+    broadcast + result all-gather over the `nccl` = RCCL backend) with a 1-rank process group: what
+    one GPU can execute of BASELINE.json configs[3].  Validation of the input happens on this path too."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from whenet_hip.shard import ShardedWHENet, broadcast_bytes
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        assert broadcast_bytes(blob[:4096], 0, dev) == blob[:4096]
+        m = ShardedWHENet(blob, dtype="f32", device=0, comm_device=dev)
+        assert m.world == 1 and m._model is not None
+        y, p, r = m.get_angle(golden["crops"])
+        assert np.abs(np.stack([y, p, r], 1) - golden["expected"]["angles"]).max() <= F32_DEG
+        ypr, am = m.forward_local(golden["crops"][2:5], global_batch=False)
+        assert np.array_equal(ypr[:, 0], y[2:5]) and am.shape == (3, 3)
+        e, _ = m.forward_local(golden["crops"][:0], global_batch=False)
+        assert e.shape == (0, 3)
+        with pytest.raises(ValueError):
+            m.get_angle(np.zeros((2, 100, 100, 3), np.uint8))          # would have read out of bounds
+        with pytest.raises(ValueError):
+            m.get_angle(np.zeros((2, 224, 224, 3), np.float32) + 0.5)  # bytes reinterpretation
+        # a float array holding byte values is converted, not reinterpreted
+        yf, _, _ = m.get_angle(golden["crops"].astype(np.float32))
+        assert np.array_equal(yf, y)
+        m.close()
+    finally:
+        dist.destroy_process_group()
 
 
 def test_snapshot_file_roundtrip(weights_file, golden):

@@ -36,14 +36,44 @@ def test_positional_pairing_rejects_mismatches(weights):
         keras_h5.convert_layers([(("dense_1" if n == "yaw_new" else n), w) for n, w in layers])
 
 
+def shuffled_heads(layers, order=("roll_new", "yaw_new", "pitch_new")):
+    """The same file with the three Dense heads stored in another order (same-depth layers of the
+    Keras graph may be serialised in any order): name matching, not position, must place them."""
+    body = [l for l in layers if l[0] not in order]
+    by = dict(layers)
+    return body + [(n, by[n]) for n in order]
+
+
+def test_heads_are_matched_by_name_not_position(weights):
+    layers = shuffled_heads(keras_h5.to_keras_layers(weights))
+    assert [ln for ln, _ in layers][-3:] == ["roll_new", "yaw_new", "pitch_new"]
+    back = keras_h5.convert_layers(layers)
+    assert all(np.array_equal(back[t.name], weights[t.name]) for t in spec.tensors())
+
+
 @needs_h5py
-def test_h5_roundtrip_through_hdf5(weights, tmp_path):
+def test_h5_roundtrip_through_hdf5(weights, tmp_path, monkeypatch):
     h5 = str(tmp_path / "WHENet.h5")
     keras_h5.write_keras_h5(h5, keras_h5.to_keras_layers(weights, offset=82))   # as if built second in a session
     blob = keras_h5.load_as_packed(h5)
     assert W.checksum(W.unpack(blob)) == W.checksum(weights)
-    assert os.path.exists(h5 + ".whnp")                         # cached for the next construction
-    assert keras_h5.load_as_packed(h5) == blob
+    assert not os.path.exists(h5 + ".whnp")                     # caching is opt-in
+    # opt-in cache, keyed on the CONTENT of the .h5 (ADVICE r1): a replaced file is re-converted
+    # whatever its mtime, a stray .whnp without a matching digest is ignored
+    monkeypatch.setenv("WHENET_H5_CACHE", "1")
+    assert keras_h5.load_as_packed(h5) == blob and os.path.exists(h5 + ".whnp") and os.path.exists(h5 + ".whnp.sha256")
+    other = dict(weights)
+    other["yaw/bias"] = other["yaw/bias"] + 1.0
+    st = os.stat(h5)
+    keras_h5.write_keras_h5(h5, keras_h5.to_keras_layers(other))
+    os.utime(h5, (st.st_atime, st.st_mtime - 1000))             # older than the cache, as `cp -p` would leave it
+    blob2 = keras_h5.load_as_packed(h5)
+    assert W.checksum(W.unpack(blob2)) == W.checksum(other) != W.checksum(weights)
+    with open(h5 + ".whnp", "wb") as f:                         # poisoned cache: digest no longer matches the blob,
+        f.write(blob)                                           # but it matches the file -> detectable only by key
+    with open(h5 + ".whnp.sha256", "w") as f:
+        f.write("0" * 64)
+    assert keras_h5.load_as_packed(h5) == blob2
     with pytest.raises(ValueError):
         p = tmp_path / "junk.h5"
         p.write_bytes(b"not hdf5 at all")

@@ -6,6 +6,8 @@ these tests pin it the only ways available here:
     transformers, torch) fed the same weights produces the same 7x7x1280 features,
   * the reference's own pre/post-processing lines restated literally.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -103,68 +105,35 @@ def test_conv_same_padding_against_torch():
 
 
 def test_hf_efficientnet_cross_check(weights, golden):
-    """Independent implementation: transformers' EfficientNet (B0 config) with our weights
-    must give the same 7x7x1280 feature map as oracle.backbone()."""
-    tr = pytest.importorskip("transformers")
-    import torch
-    cfg = tr.EfficientNetConfig(
-        num_channels=3, image_size=224, width_coefficient=1.0, depth_coefficient=1.0, depth_divisor=8,
-        kernel_sizes=[3, 3, 5, 3, 5, 5, 3], in_channels=[32, 16, 24, 40, 80, 112, 192],
-        out_channels=[16, 24, 40, 80, 112, 192, 320], depthwise_padding=[],
-        strides=[1, 2, 2, 2, 1, 2, 1], num_block_repeats=[1, 2, 2, 3, 3, 4, 1],
-        expand_ratios=[1, 6, 6, 6, 6, 6, 6], squeeze_expansion_ratio=0.25, hidden_act="swish",
-        hidden_dim=1280, pooling_type="mean", batch_norm_eps=1e-3, batch_norm_momentum=0.99,
-        dropout_rate=0.2, drop_connect_rate=0.2)
-    model = tr.EfficientNetModel(cfg).eval().double()
-    sd = model.state_dict()
-
-    def conv(name):      # HWIO -> OIHW
-        return torch.from_numpy(np.transpose(weights[name], (3, 2, 0, 1)).copy()).double()
-
-    def dwk(name):       # (kh,kw,C,1) -> (C,1,kh,kw)
-        return torch.from_numpy(np.transpose(weights[name], (2, 3, 0, 1)).copy()).double()
-
-    def vec(name):
-        return torch.from_numpy(weights[name].copy()).double()
-
-    new = {}
-
-    def put_bn(dst, src):
-        new[f"{dst}.weight"] = vec(f"{src}/gamma")
-        new[f"{dst}.bias"] = vec(f"{src}/beta")
-        new[f"{dst}.running_mean"] = vec(f"{src}/mean")
-        new[f"{dst}.running_var"] = vec(f"{src}/var")
-
-    new["embeddings.convolution.weight"] = conv("stem/conv/kernel")
-    put_bn("embeddings.batchnorm", "stem/bn")
-    for i, b in enumerate(spec.blocks()):
-        p, q = f"encoder.blocks.{i}", f"b{b.index}"
-        if b.has_expand:
-            new[f"{p}.expansion.expand_conv.weight"] = conv(f"{q}/expand/kernel")
-            put_bn(f"{p}.expansion.expand_bn", f"{q}/expand_bn")
-        new[f"{p}.depthwise_conv.depthwise_conv.weight"] = dwk(f"{q}/dw/kernel")
-        put_bn(f"{p}.depthwise_conv.depthwise_norm", f"{q}/dw_bn")
-        new[f"{p}.squeeze_excite.reduce.weight"] = conv(f"{q}/se_reduce/kernel")
-        new[f"{p}.squeeze_excite.reduce.bias"] = vec(f"{q}/se_reduce/bias")
-        new[f"{p}.squeeze_excite.expand.weight"] = conv(f"{q}/se_expand/kernel")
-        new[f"{p}.squeeze_excite.expand.bias"] = vec(f"{q}/se_expand/bias")
-        new[f"{p}.projection.project_conv.weight"] = conv(f"{q}/project/kernel")
-        put_bn(f"{p}.projection.project_bn", f"{q}/project_bn")
-    new["encoder.top_conv.weight"] = conv("head/conv/kernel")
-    put_bn("encoder.top_bn", "head/bn")
-    missing = [k for k in sd if k not in new and "num_batches_tracked" not in k]
-    assert not missing, missing[:5]
-    for k, v in new.items():
-        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
-    model.load_state_dict(new, strict=False)
-
+    """Independent implementation: transformers' EfficientNet (B0 config) with our weights must give
+    the same 7x7x1280 feature map as oracle.backbone().  A HARD requirement where this suite runs
+    (the build box has transformers): a missing package is a failure, not a skip -- this is the only
+    third-party check the oracle's backbone has."""
+    try:
+        import transformers  # noqa: F401
+    except ImportError as e:          # pragma: no cover
+        pytest.fail(f"transformers is required for the oracle's independent cross-check: {e}")
+    from tests.hf_reference import hf_backbone_features
     crops = golden["crops"][:2]
     x = O.normalise(crops).astype(np.float64)
     ours = O.backbone(x, weights)
-    with torch.no_grad():
-        hf = model(torch.from_numpy(x).permute(0, 3, 1, 2)).last_hidden_state.permute(0, 2, 3, 1).numpy()
+    hf = hf_backbone_features(weights, x)
     assert hf.shape == ours.shape == (2, 7, 7, 1280)
     np.testing.assert_allclose(hf, ours, rtol=0, atol=1e-9)
+    # and the committed fixture (what the GPU box checks against) is this very tensor
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "hf_features.npz"))
+    assert np.array_equal(fx["crop_index"], [0, 1])
+    np.testing.assert_allclose(fx["features"], hf.astype(np.float32), rtol=0, atol=0)
+
+
+def test_oracle_matches_committed_hf_fixture(weights, golden):
+    """The same check without transformers: oracle backbone vs the committed HuggingFace features
+    (tests/golden/hf_features.npz, float32, written by tests/golden/make_hf_fixture.py)."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "hf_features.npz"))
+    x = O.normalise(golden["crops"][fx["crop_index"]]).astype(np.float64)
+    ours = O.backbone(x, weights)
+    scale = np.abs(ours).max()
+    assert np.abs(ours - fx["features"]).max() <= 2e-7 * scale + 1e-7      # float32 storage rounding only
 
 
 def test_oracle_class_surface(weights, golden):

@@ -64,12 +64,29 @@ def _worker(rank, world, port, n, q):
     crops = synth.scene_crops(n, seed=11)           # every rank builds the same global batch
     y, p, r = m.get_angle(crops)
     lo, hi = m.bounds(n)
+    # the pre-sharded form (each rank hands over ITS shard, as bench.py / a per-GPU feeder does): same
+    # rows; a rank whose shard is empty (n < world) must not call the forward at all
+    before = len(calls)
+    mine, am = m.forward_local(crops[lo:hi], global_batch=False)
+    assert mine.shape == (hi - lo, 3) and am.shape == (hi - lo, 3)
+    assert np.array_equal(mine[:, 0], y[lo:hi]) and np.array_equal(mine[:, 2], r[lo:hi])
+    assert len(calls) == before + (1 if hi > lo else 0)
+    del calls[before:]
+    # float arrays holding byte values are converted (never reinterpreted); wrong shapes are refused
+    yf, _, _ = m.get_angle(crops.astype(np.float32))
+    assert np.array_equal(yf, y)
+    del calls[before:]
+    try:
+        m.get_angle(np.zeros((n, 64, 64, 3), np.uint8))
+        raise AssertionError("bad shape accepted")
+    except ValueError:
+        pass
     q.put((rank, W.checksum(w), calls, (lo, hi), np.stack([y, p, r], 1)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [3, 4])
+@pytest.mark.parametrize("n", [1, 3, 4])
 def test_sharded_get_angle_matches_single_process(weights, n):
     from whenet_hip import synth, weights as W
     from oracle import whenet_oracle as O
@@ -89,7 +106,7 @@ def test_sharded_get_angle_matches_single_process(weights, n):
     seen = 0
     for rank, csum, calls, (lo, hi), ang in sorted(res, key=lambda t: t[0]):
         assert csum == W.checksum(weights)                  # broadcast delivered the snapshot intact
-        assert calls == [hi - lo] and (lo, hi) == shard_bounds(n, world, rank)
+        assert calls == ([hi - lo] if hi > lo else []) and (lo, hi) == shard_bounds(n, world, rank)
         seen += hi - lo
         assert ang.shape == (n, 3)
         assert np.array_equal(ang, ref_ang)                 # every rank holds the full, ordered result

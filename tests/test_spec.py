@@ -3,6 +3,7 @@ instead", item 2): parameter counts, array count, MAC total, TF-SAME padding."""
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
+from oracle import b0_spec as G
 from whenet_hip import spec
 
 
@@ -60,3 +61,33 @@ def test_same_pad_properties(n, k, s):
     # the last window fits exactly inside the padded input, and no padding is wasted
     need = (out - 1) * s + k
     assert pb + pa == max(need - n, 0)
+
+
+def test_oracle_geometry_is_independent_and_agrees():
+    """oracle/b0_spec.py decodes efficientnet's own block strings; whenet_hip/spec.py carries the
+    product's table (and csrc/spec.h a third copy, compared through the C ABI in
+    tests/test_capi_cpu.py).  The checker must not import the product's geometry -- and the tables
+    must agree."""
+    import os
+    import re
+    here = os.path.dirname(os.path.abspath(G.__file__))
+    for f in os.listdir(here):
+        if f.endswith(".py"):
+            src = open(os.path.join(here, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+(whenet_hip|whenet)\b", src, re.M), f
+    ours, theirs = G.mbconv_blocks(), spec.blocks()
+    assert len(ours) == len(theirs) == 16
+    for a, b in zip(ours, theirs):
+        assert (a.number, a.kernel, a.stride, a.expand, a.filters_in, a.filters_out, a.size_in, a.size_out) == \
+               (b.index, b.k, b.s, b.expand, b.cin, b.cout, b.h_in, b.h_out)
+        assert (a.filters_mid, a.se_width, a.expands, a.identity_skip) == (b.cexp, b.se_reduced, b.has_expand, b.has_skip)
+        assert G.tf_same(a.size_in, a.kernel, a.stride) == spec.same_pad(b.h_in, b.k, b.s)
+    assert G.BN_EPSILON == spec.BN_EPS and G.INPUT_SIZE == spec.IMG
+    assert tuple(G.IMAGENET_MEAN) == spec.MEAN and tuple(G.IMAGENET_STD) == spec.STD
+    assert tuple(n for _, n in G.BINS) == (spec.N_YAW, spec.N_PITCH, spec.N_ROLL)
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 300), st.sampled_from([1, 3, 5, 7]), st.sampled_from([1, 2, 3]))
+def test_two_same_pad_statements_agree(n, k, s):
+    assert G.tf_same(n, k, s) == spec.same_pad(n, k, s)

@@ -6,7 +6,7 @@ into the WHNPACK1 container libwhenet_hip.so reads.
 
 Needs h5py, either in this interpreter or in $WHENET_H5PY_PYTHON (default
 /opt/conda/bin/python3.9).  `WHENet('WHENet.h5')` in the drop-in module does the same
-conversion on the fly and caches it as WHENet.h5.whnp.
+conversion on the fly (cached as WHENet.h5.whnp only with WHENET_H5_CACHE=1).
 """
 import os
 import sys
