@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--no-serial", action="store_true", help="skip the serial-schedule reference region")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent sub-batch chains per forward (0 = engine default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
-                    help="engine option passed to whenet_set_option (e.g. tail=1)")
+                    help="engine option passed to whenet_set_option (e.g. trunk=0)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dump-layers", default="", help="write the per-launch profile (JSON) to this path")
     return ap.parse_args()

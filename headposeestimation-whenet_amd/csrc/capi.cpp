@@ -275,10 +275,10 @@ int whenet_op_head(whenet_t* h, const float* in, int n, float* feat, float* logi
     return guarded(h, [&](whenet::Engine& e) { e.op_head(in, n, feat, logits, ypr, argmax); });
 }
 
-int whenet_op_tail(whenet_t* h, const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
+int whenet_op_trunk(whenet_t* h, const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
                    int32_t* argmax, uint64_t* timing) {
     return guarded(h, [&](whenet::Engine& e) {
-        e.op_tail(in, n, nblk, x_out, feat, logits, ypr, argmax, reinterpret_cast<unsigned long long*>(timing));
+        e.op_trunk(in, n, nblk, x_out, feat, logits, ypr, argmax, reinterpret_cast<unsigned long long*>(timing));
     });
 }
 

@@ -84,8 +84,8 @@ class Engine {
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
-    void op_tail(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr, int32_t* argmax,
-                 unsigned long long* timing);
+    void op_trunk(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr, int32_t* argmax,
+                  unsigned long long* timing);
 
     void* dev_alloc(size_t nbytes);
     void dev_free(void* p);
@@ -126,11 +126,16 @@ class Engine {
     View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
     void enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
-                         hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr);
+                         hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr, bool front_only = false);
+    const void* block6_out(const View& v) const { return v.x0; }      // 6 blocks from x0: x0 -> x1 -> ... -> x0
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
                        LaunchRecorder* rec);
-    TailArgs tail_args(const View& v, const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr,
-                       int32_t* d_amax, float* dump_x) const;
+    TrunkArgs trunk_args(const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr, int32_t* d_amax,
+                         float* dump_x);
+    void ensure_trunk();
+    void enqueue_trunk(const void* x_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
+                       LaunchRecorder* rec, int lanes);
+    void check_trunk_error();
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
@@ -144,11 +149,19 @@ class Engine {
     int pw_impl_ = 0;
     int repeat_ = 1;
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
-    bool tail_fused_ = false;   // option "tail": blocks 7..16 + head + heads as ONE launch, one workgroup per crop
-                                // (tail.hip). Correct and tested, but a lone CU needs ~1.1 ms per crop: it only matches
-                                // the per-layer schedule at batch >= 256, so it is off by default.
-    TailBlock tail_host_[10];   // block descriptors of blocks 7..16 (host copy + device table)
-    TailBlock* d_tail_blocks_ = nullptr;    // blocks 7..16 + head + heads as one launch (option "tail")
+    bool trunk_ = true;         // option "trunk": blocks 7..16 + head + heads as ONE persistent launch, a cluster of
+                                // trunk_c_ workgroups per crop (trunk.hip); 0 = one launch per layer
+    int trunk_c_ = 4;           // option "trunk_c": workgroups per cluster (fixed per handle: it fixes the summation order)
+    TrunkBlock trunk_host_[10]; // block descriptors of blocks 7..16 (host copy + device table)
+    TrunkBlock* d_trunk_blocks_ = nullptr;
+    TrunkPlan trunk_plan_{};
+    bool trunk_ready_ = false;
+    int trunk_clusters_ = 0;    // clusters the scratch was allocated for (= CUs / trunk_c_)
+    unsigned char* trunk_scratch_ = nullptr;
+    unsigned* trunk_counters_ = nullptr;
+    int trunk_threads_ = 512;      // option "trunk_threads": lanes per trunk workgroup (512 | 1024)
+    int trunk_timing_block_ = 3;   // debug option "trunk_timing_block": block (0..9) with detailed phase stamps
+    bool trunk_used_ = false;   // a trunk launch happened since the error words were last checked
     int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")
     int min_lane_crops_ = 16;   // do not split below this many crops per chain
     std::vector<hipStream_t> lane_streams_;

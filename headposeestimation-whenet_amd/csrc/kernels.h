@@ -155,34 +155,53 @@ void build_crop_plan(const int32_t rect[4], int32_t* plan);
 void launch_crop_resize(const uint8_t* d_frame, int fw, int swap_rb, const int32_t* d_plan, int k, uint8_t* d_out,
                         hipStream_t stream);
 
-// ---- tail.hip ---------------------------------------------------------------------------
-// Blocks 7..16 + head conv + GAP + Dense + decode as ONE launch, one workgroup per crop.
-struct TailBlock {
+// ---- trunk.hip --------------------------------------------------------------------------
+// Blocks 7..16 + head conv + GAP + Dense + decode as ONE persistent launch; a crop is processed by a
+// cluster of C workgroups that split every layer's channels and synchronise only with each other.
+struct TrunkBlock {
     const void* we;  const float* be;              // expand: packed MFMA image, bias [cexp]
     const float* wd; const float* bd;              // depthwise [k*k][cexp], bias
-    const float *w1t, *b1, *w2, *b2;               // squeeze-excite
+    const float *w1t, *b1, *w2c, *b2;              // squeeze-excite: reduce [R][cexp], excite [cexp][RP] channel-major
     const void* wp;  const float* bp;              // project: packed MFMA image, bias [cout]
     int kse, nte, ksp, ntp;                        // k-steps / 32-wide tiles of the two GEMMs
-    int k, s, cin, cexp, cout, h_in, h_out, pad, r, has_skip;
+    int k, s, cin, cexp, cout, h_in, h_out, pad, r, rp, has_skip;
+    int sub_tiles;                                 // 32-channel tiles of the expanded tensor per LDS sub-chunk
+    int off_e, off_dww, off_red;                   // LDS byte offsets of E / depthwise taps / strip sums (plan_trunk)
+    int wp_lds;                                    // 1: the own k-steps of the project weights are staged in LDS
 };
-struct TailArgs {
-    const TailBlock* blk;    // [10] block descriptors in DEVICE memory (built once per handle)
-    TailBlock first, last;   // host copies of blk[0] / blk[nblk-1] (geometry the launcher needs)
-    int nblk, n;
-    const void* x_in;        // [n][14][14][80] T   (output of block 6)
-    void* d_scratch;         // per-crop depthwise-output scratch, T
-    size_t d_stride;         // elements per crop in d_scratch
+struct TrunkPlan {
+    int C;                                         // workgroups per cluster
+    int fixed_off;                                 // LDS offset of the small per-workgroup arrays
+    size_t lds_bytes;
+    size_t xmax, dmax, pmax;                       // elements: block in/out, own depthwise output, project partial
+    size_t off_d, off_p, off_r, off_l;             // byte offsets inside a cluster's scratch
+    size_t scratch_stride;                         // bytes of scratch per cluster
+};
+TrunkPlan plan_trunk(TrunkBlock* blk, int nblk, int dtype, int C, int head_nth, int head_cin);
+struct TrunkArgs {
+    const TrunkBlock* blk;   // [nblk] block descriptors in DEVICE memory (built once per handle)
+    int nblk, n, C, nclusters;
+    const void* x_in;        // output of block 6: crop c of lane l at (lane_start[l] * lane_stride +
+    size_t x_in_stride;      //   (c - lane_start[l]) * x_in_stride) elements; x_in_stride = 14*14*80
+    size_t lane_stride;      // elements the arena reserves per crop (the layer-wise front half packs each
+    int nlanes;              //   sub-batch lane contiguously from its first crop's slot)
+    int lane_start[8];
+    unsigned char* scratch;  // [nclusters][scratch_stride]
+    size_t scratch_stride, xmax, dmax, pmax, off_d, off_p, off_r, off_l;
+    unsigned* counters;      // [nclusters][16]: arrival counter, error word (zeroed by the launcher)
+    int fixed_off;
     const void* wh;  const float* bh;  int ksh, nth;   // head conv
     const float* wdense;  const float* bdense;         // [1280][252], [252]
     float* feat;             // [n][1280] or nullptr
     float* logits;           // [n][252] or nullptr
     float* ypr;              // [n][3]
     int32_t* argmax;         // [n][3] or nullptr
-    unsigned long long* timing;   // debug: [96] wall-clock stamps of crop 0's phases, or nullptr
+    unsigned long long* timing;   // debug: [192] wall-clock stamps of workgroup 0's phases, or nullptr
+    int timing_block;        // detailed stamps (timing[128..]) for this block index
     float* dump_x;           // test hook: stop after the blocks and write X as f32 [n][HW][C]
-    int fixed_off;           // filled by the launcher
 };
-void launch_tail(const TailArgs& a, const TailBlock* host_blk, int dtype, hipStream_t stream);
+void launch_trunk(const TrunkArgs& a, size_t lds_bytes, int dtype, int threads, hipStream_t stream);
+std::string kernel_name_trunk(int dtype, int threads);
 
 // ---- convert.hip ------------------------------------------------------------------------
 void launch_empty(hipStream_t stream);   // boundary calibration for whenet_profile()

@@ -54,7 +54,7 @@ _PROTOS = {
     "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
     "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "whenet_op_head": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
-    "whenet_op_tail": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "whenet_op_trunk": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "whenet_op_decode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "whenet_block_spec": (C.c_int, [C.c_int, C.POINTER(C.c_int32 * 8)]),
     "whenet_dw_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32 * 12)]),
@@ -325,7 +325,7 @@ class Handle:
         self._check(self._lib.whenet_op_head(self._h, _ptr(x), n, _ptr(feat), _ptr(lg), _ptr(ypr), _ptr(am)))
         return {"feat": feat, "logits": lg, "ypr": ypr, "argmax": am}
 
-    def op_tail(self, x: np.ndarray, nblk: int = 10, dump: bool = False):
+    def op_trunk(self, x: np.ndarray, nblk: int = 10, dump: bool = False):
         from . import spec
         x = np.ascontiguousarray(x, np.float32)
         n = x.shape[0]
@@ -333,14 +333,14 @@ class Handle:
         if dump:
             b = spec.blocks()[6 + nblk - 1]
             out = np.empty((n, b.h_out, b.h_out, b.cout), np.float32)
-            self._check(self._lib.whenet_op_tail(self._h, _ptr(x), n, nblk, _ptr(out), None, None, None, None, None))
+            self._check(self._lib.whenet_op_trunk(self._h, _ptr(x), n, nblk, _ptr(out), None, None, None, None, None))
             return out
         feat = np.empty((n, 1280), np.float32)
         lg = np.empty((n, 252), np.float32)
         ypr = np.empty((n, 3), np.float32)
         am = np.empty((n, 3), np.int32)
-        tm = np.zeros(96, np.uint64)
-        self._check(self._lib.whenet_op_tail(self._h, _ptr(x), n, 10, None, _ptr(feat), _ptr(lg), _ptr(ypr), _ptr(am), _ptr(tm)))
+        tm = np.zeros(192, np.uint64)
+        self._check(self._lib.whenet_op_trunk(self._h, _ptr(x), n, 10, None, _ptr(feat), _ptr(lg), _ptr(ypr), _ptr(am), _ptr(tm)))
         return {"feat": feat, "logits": lg, "ypr": ypr, "argmax": am, "timing": tm}
 
     def op_decode(self, logits: np.ndarray):

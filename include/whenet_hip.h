@@ -93,8 +93,11 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
  *          "fuse_front" (0/1, default 1: expand 1x1 + depthwise as ONE kernel per block, the
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
- *          "tail" (0/1, default 0: 1 = blocks 7..16 + head + heads as ONE launch, one workgroup
- *                  per crop; 0 = one launch per layer),
+ *          "trunk" (0/1, default 1: blocks 7..16 + head conv + heads as ONE persistent launch in which a
+ *                  cluster of "trunk_c" workgroups (one per CU) processes a crop, splitting every layer's
+ *                  channels and synchronising only inside the cluster; 0 = one launch per layer),
+ *          "trunk_c" (1..16, default 4 for f16 / 8 for f32: workgroups per cluster; fixed per handle
+ *                  because it fixes the summation order of the project convs),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "inflight" (1..4, default 1: n > 1 gives the handle n engines -- own streams, activation
  *                  arena, graphs, replicated weights -- and spreads whenet_forward_u8_device calls with
@@ -187,12 +190,12 @@ WHENET_API int whenet_op_block(whenet_t* h, int index, const float* in, int n,
  *   feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3] */
 WHENET_API int whenet_op_head(whenet_t* h, const float* in, int n,
                    float* feat, float* logits, float* ypr, int32_t* argmax);
-/* the fused tail launch (blocks 7..16 + head conv + GAP + Dense + decode, one workgroup per
- * crop) on input [n,14,14,80] = block 6's output.  With x_out != NULL only the first `nblk`
+/* the trunk launch alone (blocks 7..16 + head conv + GAP + Dense + decode, one cluster of workgroups
+ * per crop) on input [n,14,14,80] = block 6's output.  With x_out != NULL only the first `nblk`
  * (1..10) blocks run and their output [n,Ho,Ho,Cout] is returned; with x_out == NULL
  * (nblk must be 10) the head runs too: feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3]. */
-WHENET_API int whenet_op_tail(whenet_t* h, const float* in, int n, int nblk, float* x_out,
-                   float* feat, float* logits, float* ypr, int32_t* argmax, uint64_t* timing /* [96] or NULL */);
+WHENET_API int whenet_op_trunk(whenet_t* h, const float* in, int n, int nblk, float* x_out,
+                    float* feat, float* logits, float* ypr, int32_t* argmax, uint64_t* timing /* [192] or NULL */);
 /* decode only (whenet.py:28-33) on caller logits [n,252] -> ypr [n,3], argmax [n,3] */
 WHENET_API int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax);
 

@@ -72,7 +72,8 @@ def test_info(handle):
     i = handle.info()
     assert i.abi_version == _lib.ABI_VERSION
     assert (i.params_backbone, i.params_heads, i.n_tensors) == (4_049_564, 322_812, 315)
-    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 51   # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads
+    # stem, dw(b1), 5 front, 6 se, 6 project, trunk  (51 with option trunk=0: 15 front, 16 se, 16 project, head conv, heads)
+    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 20
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
 
@@ -120,38 +121,68 @@ def test_head_kernels(handle, taps):
 
 
 @pytest.mark.parametrize("nblk", list(range(1, 11)))
-def test_tail_megakernel_block_chain(handle, taps, nblk):
-    """The fused tail launch (blocks 7..16, one workgroup per crop), stopped after `nblk` blocks,
-    on the oracle's block-6 output: covers every phase (expand GEMM -> LDS, depthwise from LDS,
-    SE, gated project GEMM + skip) on every tail geometry (14x14 k3/k5, the stride-2 block 12,
-    7x7 k5/k3)."""
-    got = handle.op_tail(taps["b6/out"].astype(np.float32), nblk=nblk, dump=True)
+def test_trunk_kernel_block_chain(handle, taps, nblk):
+    """The trunk launch (blocks 7..16, a cluster of workgroups per crop, trunk.hip), stopped after `nblk`
+    blocks, on the oracle's block-6 output: covers every phase (X gather, expand GEMM -> LDS, depthwise
+    from LDS, SE across the cluster, gated split-K project GEMM, reduce + skip) on every geometry (14x14
+    k3/k5, the stride-2 block 12, 7x7 k5/k3)."""
+    got = handle.op_trunk(taps["b6/out"].astype(np.float32), nblk=nblk, dump=True)
     ref = taps[f"b{6 + nblk}/out"]
     assert got.shape == ref.shape
     assert rel_err(got, ref) < (1e-4 if handle.name == "f32" else 6e-2), nblk
 
 
-def test_tail_megakernel_head(handle, taps):
-    r = handle.op_tail(taps["b6/out"].astype(np.float32))
+def test_trunk_kernel_head(handle, taps):
+    r = handle.op_trunk(taps["b6/out"].astype(np.float32))
     assert rel_err(r["feat"], taps["head"].mean(axis=(1, 2))) < (1e-4 if handle.name == "f32" else 6e-2)
     assert np.abs(r["logits"] - taps["logits"]).max() < (2e-3 if handle.name == "f32" else 1.0)
     y, p, rr = O.decode(taps["logits"])
     assert np.abs(r["ypr"] - np.stack([y, p, rr], 1)).max() < (F32_DEG if handle.name == "f32" else F16_DEG)
 
 
-def test_tail_fused_vs_layerwise(handle, golden):
-    """Same network, two schedules: the fused tail launch and one launch per layer."""
+@pytest.mark.parametrize("c", [1, 2, 3, 4, 8, 16])
+def test_trunk_cluster_sizes(blob, golden, c):
+    """Any cluster size gives the same network (the channel split and the order of the split-K partial
+    sums change with it, nothing else): f32 within the parity bar for every C, incl. C = 1 (no exchange
+    partner), C = 3 (uneven tile split) and C = 16 (members with a single 32-channel tile)."""
+    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
+        h.set_option("trunk_c", c)
+        crops = np.concatenate([golden["crops"], golden["crops"][::-1]])
+        ypr, am, lg = h.forward(crops)
+        exp = golden["expected"]
+        ang = np.concatenate([exp["angles"], exp["angles"][::-1]])
+        assert np.abs(ypr - ang).max() <= F32_DEG
+        assert np.abs(lg - np.concatenate([exp["logits"], exp["logits"][::-1]])).max() < 2e-3
+        assert np.array_equal(ypr[:8], ypr[8:][::-1])          # same crop, another cluster: same bits
+
+
+def test_trunk_vs_layerwise(handle, golden):
+    """Same network, two schedules: the trunk launch and one launch per layer."""
     crops = golden["crops"]
-    ypr0, am0, lg0 = handle.forward(crops)
-    handle.set_option("tail", 1)
+    ypr1, am1, lg1 = handle.forward(crops)
+    handle.set_option("trunk", 0)
     try:
-        ypr1, am1, lg1 = handle.forward(crops)
+        ypr0, am0, lg0 = handle.forward(crops)
+        assert handle.info().n_kernels_per_forward == 51
     finally:
-        handle.set_option("tail", 0)
+        handle.set_option("trunk", 1)
+    assert handle.info().n_kernels_per_forward == 20
     assert np.abs(lg1 - lg0).max() < (2e-3 if handle.name == "f32" else 0.6)
     exp = golden["expected"]["angles"]
     for ypr in (ypr0, ypr1):
         assert np.abs(ypr - exp).max() <= (F32_DEG if handle.name == "f32" else F16_DEG)
+
+
+def test_trunk_many_crops_per_cluster(handle):
+    """More crops than clusters (each cluster loops over several crops, reusing its scratch and its
+    monotonic arrival counter): bitwise the results of the crops run one batch at a time."""
+    crops = np.concatenate([synth.scene_crops(100, seed=31), synth.noise_crops(60, seed=32)])    # 160 > 64 clusters
+    ypr, am, lg = handle.forward(crops)
+    for lo in (0, 64, 128):
+        y, a, l = handle.forward(crops[lo:lo + 64])
+        assert np.array_equal(l, lg[lo:lo + 64]) and np.array_equal(y, ypr[lo:lo + 64])
+    y1, _, l1 = handle.forward(crops[77:78])
+    assert np.array_equal(l1[0], lg[77])
 
 
 def test_decode_kernel(handle):
