@@ -200,11 +200,6 @@ void Engine::set_option(const std::string& key, long value) {
         trunk_ = value != 0;
         sync();
         drop_graphs();
-    } else if (key == "trunk_threads") {
-        WHENET_REQUIRE(value == 512 || value == 1024, WHENET_EINVAL, "trunk_threads must be 512 or 1024");
-        sync();
-        drop_graphs();
-        trunk_threads_ = int(value);
     } else if (key == "trunk_timing_block") {
         WHENET_REQUIRE(value >= 0 && value < 10, WHENET_EINVAL, "trunk_timing_block must be 0..9");
         trunk_timing_block_ = int(value);
@@ -527,6 +522,7 @@ TrunkArgs Engine::trunk_args(const void* x_in, int n, int nblk, float* feat, flo
     a.off_d = trunk_plan_.off_d;  a.off_p = trunk_plan_.off_p;  a.off_r = trunk_plan_.off_r;  a.off_l = trunk_plan_.off_l;
     a.counters = trunk_counters_;
     a.fixed_off = trunk_plan_.fixed_off;
+    a.own_cap = trunk_plan_.own_cap;
     a.wh = head_.wp;  a.bh = head_.bias;  a.ksh = head_.KS;  a.nth = head_.NTILES;
     a.wdense = d_dense_w_;  a.bdense = d_dense_b_;
     a.feat = feat;  a.logits = d_logits;  a.ypr = d_ypr;  a.argmax = d_amax;  a.dump_x = dump_x;
@@ -546,9 +542,9 @@ void Engine::enqueue_trunk(const void* x_in, int n, float* d_ypr, int32_t* d_ama
     trunk_used_ = true;
     // per crop: blocks 7-16 + head + heads = 99.6 M MACs; reads 15,680 elements in, ~1 KB out; the 3.3 M weights
     // are read once per cluster through L2
-    R("trunk", "trunk", kernel_name_trunk(dtype_, trunk_threads_).c_str(),
+    R("trunk", "trunk", kernel_name_trunk(dtype_).c_str(),
       double(n) * (196.0 * 80.0 * es + 1020.0) + 3302000.0 * es, 2.0 * n * 99.6e6,
-      [&] { launch_trunk(a, trunk_plan_.lds_bytes, dtype_, trunk_threads_, s); });
+      [&] { launch_trunk(a, trunk_plan_.lds_bytes, dtype_, s); });
 }
 
 // A cluster whose members did not all arrive within the poll bound sets its error word (trunk.hip): the
@@ -1154,10 +1150,10 @@ void Engine::op_trunk(const float* in, int n, int nblk, float* x_out, float* fea
     if (timing) {
         d_timing = static_cast<unsigned long long*>(tmp.get(192 * sizeof(unsigned long long)));
         WHENET_HIP_CHECK(hipMemsetAsync(d_timing, 0, 192 * sizeof(unsigned long long), stream_));
-        launch_trunk(a, trunk_plan_.lds_bytes, dtype_, trunk_threads_, stream_);     // warm (weights into L2), then the timed one
+        launch_trunk(a, trunk_plan_.lds_bytes, dtype_, stream_);     // warm (weights into L2), then the timed one
         a.timing = d_timing;
     }
-    launch_trunk(a, trunk_plan_.lds_bytes, dtype_, trunk_threads_, stream_);
+    launch_trunk(a, trunk_plan_.lds_bytes, dtype_, stream_);
     if (timing) WHENET_HIP_CHECK(hipMemcpyAsync(timing, d_timing, 192 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
     if (dump) {
         WHENET_HIP_CHECK(hipMemcpyAsync(x_out, d_f32, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream_));

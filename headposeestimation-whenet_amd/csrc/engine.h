@@ -149,8 +149,9 @@ class Engine {
     int pw_impl_ = 0;
     int repeat_ = 1;
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
-    bool trunk_ = true;         // option "trunk": blocks 7..16 + head + heads as ONE persistent launch, a cluster of
-                                // trunk_c_ workgroups per crop (trunk.hip); 0 = one launch per layer
+    bool trunk_ = false;        // option "trunk": blocks 7..16 + head + heads as ONE persistent launch, a cluster of
+                                // trunk_c_ workgroups per crop (trunk.hip).  Correct and tested; measured slower than
+                                // one launch per layer at every batch size, so it is off by default
     int trunk_c_ = 4;           // option "trunk_c": workgroups per cluster (fixed per handle: it fixes the summation order)
     TrunkBlock trunk_host_[10]; // block descriptors of blocks 7..16 (host copy + device table)
     TrunkBlock* d_trunk_blocks_ = nullptr;
@@ -159,7 +160,6 @@ class Engine {
     int trunk_clusters_ = 0;    // clusters the scratch was allocated for (= CUs / trunk_c_)
     unsigned char* trunk_scratch_ = nullptr;
     unsigned* trunk_counters_ = nullptr;
-    int trunk_threads_ = 512;      // option "trunk_threads": lanes per trunk workgroup (512 | 1024)
     int trunk_timing_block_ = 3;   // debug option "trunk_timing_block": block (0..9) with detailed phase stamps
     bool trunk_used_ = false;   // a trunk launch happened since the error words were last checked
     int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")

@@ -166,12 +166,15 @@ struct TrunkBlock {
     int kse, nte, ksp, ntp;                        // k-steps / 32-wide tiles of the two GEMMs
     int k, s, cin, cexp, cout, h_in, h_out, pad, r, rp, has_skip;
     int sub_tiles;                                 // 32-channel tiles of the expanded tensor per LDS sub-chunk
-    int off_e, off_dww, off_red;                   // LDS byte offsets of E / depthwise taps / strip sums (plan_trunk)
+    int dbuf;                                      // 1: two E / taps / strip-sum buffers (expand(s+1) beside taps(s))
+    int vc;                                        // channels per depthwise lane-task (2 | 4)
+    int off_e, e_bytes, off_dww, off_red;          // LDS byte offsets of E / depthwise taps / strip sums (plan_trunk)
     int wp_lds;                                    // 1: the own k-steps of the project weights are staged in LDS
 };
 struct TrunkPlan {
     int C;                                         // workgroups per cluster
     int fixed_off;                                 // LDS offset of the small per-workgroup arrays
+    int own_cap;                                   // largest channel share of a member over all blocks
     size_t lds_bytes;
     size_t xmax, dmax, pmax;                       // elements: block in/out, own depthwise output, project partial
     size_t off_d, off_p, off_r, off_l;             // byte offsets inside a cluster's scratch
@@ -189,7 +192,7 @@ struct TrunkArgs {
     unsigned char* scratch;  // [nclusters][scratch_stride]
     size_t scratch_stride, xmax, dmax, pmax, off_d, off_p, off_r, off_l;
     unsigned* counters;      // [nclusters][16]: arrival counter, error word (zeroed by the launcher)
-    int fixed_off;
+    int fixed_off, own_cap;
     const void* wh;  const float* bh;  int ksh, nth;   // head conv
     const float* wdense;  const float* bdense;         // [1280][252], [252]
     float* feat;             // [n][1280] or nullptr
@@ -200,8 +203,8 @@ struct TrunkArgs {
     int timing_block;        // detailed stamps (timing[128..]) for this block index
     float* dump_x;           // test hook: stop after the blocks and write X as f32 [n][HW][C]
 };
-void launch_trunk(const TrunkArgs& a, size_t lds_bytes, int dtype, int threads, hipStream_t stream);
-std::string kernel_name_trunk(int dtype, int threads);
+void launch_trunk(const TrunkArgs& a, size_t lds_bytes, int dtype, hipStream_t stream);
+std::string kernel_name_trunk(int dtype);
 
 // ---- convert.hip ------------------------------------------------------------------------
 void launch_empty(hipStream_t stream);   // boundary calibration for whenet_profile()

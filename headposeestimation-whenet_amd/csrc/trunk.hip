@@ -47,12 +47,24 @@ namespace whenet {
 
 namespace {
 
-constexpr int MAXW = 16;      // waves per workgroup of the widest instantiation (1024 lanes)
+constexpr int TNT = 512;       // lanes per workgroup: 8 waves, 2 per SIMD, 256 registers per lane (nothing spills; the
+constexpr int TNW = TNT / 64;  // 1024-lane build spilled ~100 registers around every phase boundary and measured slower).
+                               // A wave issues one VALU instruction per ~5.3 cycles (tools/probes/valu_probe.hip) and
+                               // every phase is a chain of dependent memory / LDS / matrix latencies: a phase is as
+                               // fast as its slowest wave, so the work is cut into about one task per wave
+constexpr int RW = TNW / 2, RT = TNT / 2;     // waves / lanes of one role in the pipelined front phase
 constexpr int P = 7;
-constexpr int VC = 4;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Pointers that come out of the block table in memory are generic to the compiler: every access through them
+// would be a FLAT load (address-space check, counted on both the vector-memory and the LDS counter, so an
+// `s_waitcnt` for an LDS read also waits for them).  All of them point to device memory: say so.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename U> __device__ __forceinline__ const U GLOBAL_AS* gptr(const void* p) {
+    return (const U GLOBAL_AS*)(p);
+}
 
 // ---- write-through / L1-bypassing accesses of exchanged data -------------------------------------
 struct Buf {                  // wave-uniform buffer descriptor + helpers (offsets in bytes)
@@ -63,16 +75,16 @@ struct Buf {                  // wave-uniform buffer descriptor + helpers (offse
     __device__ __forceinline__ void st16(unsigned off, u32x4 v) const { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
 };
 __device__ __forceinline__ float ld_sc1_f32(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const float GLOBAL_AS*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_sc1_f32(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((float GLOBAL_AS*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long ld_sc1_u64(const void* p) {
-    return __hip_atomic_load(static_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const unsigned long long GLOBAL_AS*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_sc1_u64(void* p, unsigned long long v) {
-    __hip_atomic_store(static_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((unsigned long long GLOBAL_AS*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T> __device__ __forceinline__ typename Vec<T>::type as_vec(u32x4 v) {
@@ -111,36 +123,6 @@ __device__ __forceinline__ void cluster_wait(unsigned* counter, unsigned target,
     __syncthreads();
 }
 
-// L2 warm-up of weights that a LATER phase reads: one dword per 128-byte line, destination parked in a
-// register until touch_retire().  Every weight of this kernel is read once per crop, so without this each
-// phase's first use pays a full memory round trip (~1 us measured); a touch a block ahead turns those into
-// L2 hits.
-constexpr int NTOUCH = 6;
-struct Touch {
-    unsigned r[NTOUCH];
-};
-struct TouchRegion {          // rows x row_bytes, row pitch pitch_bytes
-    const char* base;
-    int lpr, lines, pitch;
-    __device__ __forceinline__ TouchRegion(const void* b, int rows, int row_bytes, int pitch_bytes)
-        : base(static_cast<const char*>(b)), lpr((row_bytes + 127) >> 7), lines(rows * ((row_bytes + 127) >> 7)),
-          pitch(pitch_bytes) {}
-    __device__ __forceinline__ const char* line(int i) const {
-        const int r = i / lpr, c = i - r * lpr;
-        return base + size_t(r) * pitch + c * 128;
-    }
-};
-// (a compiler-visible load: hipcc tracks its destination register and waits for it only at touch_retire's
-// use; the empty asm with a memory clobber keeps the load from being sunk down to that use)
-__device__ __forceinline__ void touch_line(unsigned& dst, const void* p) {
-    dst = *static_cast<const unsigned*>(p);
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void touch_retire(Touch& t) {
-#pragma unroll
-    for (int u = 0; u < NTOUCH; ++u) asm volatile("" ::"v"(t.r[u]));
-}
-
 // contiguous, balanced split of `total` items over `parts`; part `i` gets [lo, lo + cnt)
 __host__ __device__ inline void split_range(int total, int parts, int i, int* lo, int* cnt) {
     const int base = total / parts, extra = total % parts;
@@ -151,37 +133,40 @@ __host__ __device__ inline void split_range(int total, int parts, int i, int* lo
 __host__ __device__ constexpr int align16(int x) { return (x + 15) & ~15; }
 
 // ---- one (strip, tile) GEMM task: acc += sum_k W[tile][k] * act[row][k] ---------------------------
-// U weight fragments (global, 1 KiB per wave each) are in flight before the first MFMA of a group; the
-// activation fragments come from LDS.
+// Software-pipelined by hand: the U weight fragments AND the U activation fragments of a group are
+// requested before its first MFMA (a dependent LDS round trip per MFMA otherwise: ~280 cycles per k-step
+// measured).
 template <typename T, int U, typename LoadW, typename LoadA>
 __device__ __forceinline__ void gemm_task(float16v& acc, int ks0, int ks1, LoadW&& load_w, LoadA&& load_a) {
     using VT = typename Vec<T>::type;
     for (int ks = ks0; ks < ks1; ks += U) {
-        VT w[U];
+        VT w[U], av[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) w[u] = (ks + u < ks1) ? load_w(ks + u) : vec_zero<T>();
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (ks + u < ks1) {                       // (wave-uniform)
-                const VT av = load_a(ks + u);
-                Mfma<T>::step(w[u], av, acc);
-            }
-        }
+        for (int u = 0; u < U; ++u) av[u] = (ks + u < ks1) ? load_a(ks + u) : vec_zero<T>();
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ks + u < ks1) Mfma<T>::step(w[u], av[u], acc);      // (wave-uniform)
     }
 }
 
-// ---- depthwise taps of one sub-chunk: E (LDS) -> D (own global scratch), strip channel sums -> s_red
-template <typename T, int K, int S, int TNT>
-__device__ __forceinline__ void dw_chunk(const unsigned char* __restrict__ E, int EW, int EP, T* __restrict__ D,
-                                         int dpitch, int dcol0, const float* __restrict__ s_dww,
+// ---- depthwise taps of one sub-chunk: E (LDS, f32) -> D (own global scratch), strip channel sums -> s_red
+// lane-task = VC channels x strip of 7 output pixels.  The expanded activation is kept in f32 in LDS: the
+// taps are pure f32 FMAs on ds_read_b128 operands (a v_cvt_f32_f16 costs as much as two FMAs on this chip),
+// and the expanded tensor is never rounded to the activation type at all.
+template <typename T, int K, int S, int VC>
+__device__ __forceinline__ void dw_tasks(const unsigned char* __restrict__ E, int EW, int EP, T* __restrict__ D,
+                                         int dpitch, int dcol0, const float* __restrict__ s_dww, int wpitch,
                                          const float* __restrict__ s_bd, float* __restrict__ s_red, int Ho, int ccur,
-                                         int tid) {
+                                         int t_lo, int t_n) {
     using VCT = T __attribute__((ext_vector_type(VC)));
+    typedef float floatc __attribute__((ext_vector_type(VC)));
     constexpr int NIX = (P - 1) * S + K;
     const int CG = ccur / VC;
     const int spr = Ho / P;                          // strips per output row
     const int nstrip = Ho * spr;
-    for (int lt = tid; lt < CG * nstrip; lt += TNT) {
+    for (int lt = t_lo; lt < CG * nstrip; lt += t_n) {
         const int cg = lt % CG;
         const int sidx = lt / CG;
         const int oy = sidx / spr;
@@ -191,34 +176,31 @@ __device__ __forceinline__ void dw_chunk(const unsigned char* __restrict__ E, in
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int v = 0; v < VC; ++v) acc[p][v] = 0.0f;
-#pragma unroll 1   // one kernel row at a time: keeps this phase's register footprint small
+#pragma unroll 1   // one kernel row at a time: bounds the register footprint (K taps + NIX inputs in flight)
         for (int ky = 0; ky < K; ++ky) {
-            float wr[K][VC];
+            floatc wr[K];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float4v wv = *reinterpret_cast<const float4v*>(s_dww + (ky * K + kx) * ccur + cg * VC);
+            for (int kx = 0; kx < K; ++kx) wr[kx] = *reinterpret_cast<const floatc*>(s_dww + (ky * K + kx) * wpitch + cg * VC);
+            const unsigned char* row = E + size_t((oy * S + ky) * EW + sx * P * S) * EP + cg * VC * 4;
+            floatc xin[NIX];
 #pragma unroll
-                for (int v = 0; v < VC; ++v) wr[kx][v] = wv[v];
-            }
-            const unsigned char* row = E + size_t((oy * S + ky) * EW + sx * P * S) * EP + cg * VC * sizeof(T);
+            for (int ix = 0; ix < NIX; ++ix) xin[ix] = *reinterpret_cast<const floatc*>(row + size_t(ix) * EP);
 #pragma unroll
             for (int ix = 0; ix < NIX; ++ix) {
-                const VCT xv = *reinterpret_cast<const VCT*>(row + size_t(ix) * EP);
-                float x[VC];
-#pragma unroll
-                for (int v = 0; v < VC; ++v) x[v] = float(xv[v]);
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     const int d = ix - kx;
                     if (d >= 0 && (d % S) == 0 && (d / S) < P) {
 #pragma unroll
-                        for (int v = 0; v < VC; ++v) acc[d / S][v] = fmaf(x[v], wr[kx][v], acc[d / S][v]);
+                        for (int v = 0; v < VC; ++v) acc[d / S][v] = fmaf(xin[ix][v], wr[kx][v], acc[d / S][v]);
                     }
                 }
             }
         }
-        const float4v bs = *reinterpret_cast<const float4v*>(s_bd + cg * VC);
-        float sum[VC] = {0.f, 0.f, 0.f, 0.f};
+        const floatc bs = *reinterpret_cast<const floatc*>(s_bd + cg * VC);
+        floatc sum;
+#pragma unroll
+        for (int v = 0; v < VC; ++v) sum[v] = 0.f;
         T* dst = D + (size_t(oy) * Ho + sx * P) * dpitch + dcol0 + cg * VC;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -231,16 +213,15 @@ __device__ __forceinline__ void dw_chunk(const unsigned char* __restrict__ E, in
             }
             *reinterpret_cast<VCT*>(dst + size_t(p) * dpitch) = o;
         }
-#pragma unroll
-        for (int v = 0; v < VC; ++v) s_red[sidx * ccur + cg * VC + v] = sum[v];
+        *reinterpret_cast<floatc*>(s_red + sidx * wpitch + cg * VC) = sum;
     }
 }
 
-// TNT lanes per workgroup: 1024 (4 waves per SIMD, 128 registers per lane) or 512 (2 waves per SIMD, 256
-// registers: nothing spills, deeper prefetch per wave)
-template <typename T, int TNT>
+// Barriers inside the kernel order LDS traffic only (lds_barrier: no vmcnt drain -- a __syncthreads() after
+// the depthwise phase waited ~3 us for the acknowledgements of its global stores); global data is published
+// by cluster_arrive, which drains explicitly.
+template <typename T>
 __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
-    constexpr int TNW = TNT / 64;
     constexpr int V = Vec<T>::V;
     constexpr int SZ = int(sizeof(T));
     constexpr int KPT = 32 / (2 * V);                 // k-steps per 32-channel tile (f16: 2, f32: 4)
@@ -267,92 +248,20 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
     unsigned phase = 0;                                // C * (cluster barriers ARRIVED at so far)
 
     // small per-workgroup arrays at the top of the LDS allocation (all block layouts stay below)
-    float* s_sum = reinterpret_cast<float*>(smem + a.fixed_off);      // [1152] own channel sums
-    float* s_gate = s_sum + 1152;                                      // [1152] own gate
-    float* s_r = s_gate + 1152;                                        // [64]
-    float* s_be = s_r + 64;                                            // [1152] expand bias of the own channels
-    float* s_bd = s_be + 1152;                                         // [1152] depthwise bias of the own channels
+    float* s_sum = reinterpret_cast<float*>(smem + a.fixed_off);      // [own_cap] own channel sums
+    float* s_be = s_sum + a.own_cap;                                   // [own_cap] expand bias of the own channels
+    float* s_bd = s_be + a.own_cap;                                    // [own_cap] depthwise bias of the own channels
+    T* s_gate = reinterpret_cast<T*>(s_bd + a.own_cap);               // [own_cap] own gate, in the activation type
+    float* s_r = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(s_gate) + a.own_cap * 4);   // [64]
 
     auto stamp = [&](int slot) {
         if (a.timing != nullptr && blockIdx.x == 0 && tid == 0) a.timing[slot] = wall_clock64();
     };
 
-    // set-up of an expand/depthwise sub-chunk that does not depend on the block input: zero E (the halo is
-    // TF 'SAME' padding of the EXPANDED tensor), park the chunk's depthwise taps in LDS
-    auto setup_chunk = [&](const TrunkBlock& B, int c0, int ccur) {
-        const int EW = (B.h_out - 1) * B.s + B.k;
-        const int EP = ccur * SZ + 16;
-        unsigned char* E = smem + B.off_e;
-        float* s_dww = reinterpret_cast<float*>(smem + B.off_dww);
-        const int ntap = B.k * B.k * ccur;
-        for (int i0 = tid; i0 < ntap; i0 += 4 * TNT) {
-            float wv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * TNT;
-                const int tap = i / ccur, c = i - tap * ccur;
-                wv[u] = (i < ntap) ? B.wd[size_t(tap) * B.cexp + c0 + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i0 + u * TNT < ntap) s_dww[i0 + u * TNT] = wv[u];
-        }
-        for (int i = tid; i < EW * EW * EP / 16; i += TNT) reinterpret_cast<VT*>(E)[i] = vec_zero<T>();
-    };
-
-    // L2 warm-up of everything block `bi` (or, bi == nblk, the head) will read of the weights: lines
-    // tid, tid + TNT, .. of the concatenation of the member's weight regions
-    Touch touch;
-#pragma unroll
-    for (int u = 0; u < NTOUCH; ++u) touch.r[u] = 0;
-    auto touch_block = [&](int bi) {
-        if (bi > a.nblk) return;
-        if (bi == a.nblk) {
-            if (a.dump_x != nullptr) return;
-            int ht0, htcnt;
-            split_range(a.nth, C, m, &ht0, &htcnt);
-            const TouchRegion rg[3] = {
-                TouchRegion(static_cast<const char*>(a.wh) + size_t(ht0) * 1024, a.ksh, htcnt * 1024, a.nth * 1024),
-                TouchRegion(a.wdense + size_t(ht0) * 32 * N_LOGITS, 1, htcnt * 32 * N_LOGITS * 4, 0),
-                TouchRegion(a.bh + ht0 * 32, 1, htcnt * 32 * 4, 0)};
-#pragma unroll
-            for (int u = 0; u < NTOUCH; ++u) {
-                int v = tid + u * TNT;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (v >= 0 && v < rg[q].lines) touch_line(touch.r[u], rg[q].line(v));
-                    v -= rg[q].lines;
-                }
-            }
-            return;
-        }
-        const TrunkBlock N = a.blk[bi];
-        int t0, tcnt;
-        split_range(N.cexp >> 5, C, m, &t0, &tcnt);
-        const int own = tcnt * 32, c0 = t0 * 32;
-        const TouchRegion rg[8] = {
-            TouchRegion(static_cast<const char*>(N.we) + size_t(t0) * 1024, N.kse, tcnt * 1024, N.nte * 1024),
-            TouchRegion(N.wd + c0, N.k * N.k, own * 4, N.cexp * 4),
-            TouchRegion(N.w1t + c0, N.r, own * 4, N.cexp * 4),
-            TouchRegion(N.w2c + size_t(c0) * N.rp, 1, own * N.rp * 4, 0),
-            TouchRegion(static_cast<const char*>(N.wp) + size_t(t0) * KPT * N.ntp * 1024, 1, tcnt * KPT * N.ntp * 1024, 0),
-            TouchRegion(N.b2 + c0, 1, own * 4, 0),
-            TouchRegion(N.bp, 1, N.cout * 4, 0),
-            TouchRegion(N.b1, 1, N.r * 4, 0)};
-#pragma unroll
-        for (int u = 0; u < NTOUCH; ++u) {
-            int v = tid + u * TNT;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (v >= 0 && v < rg[q].lines) touch_line(touch.r[u], rg[q].line(v));
-                v -= rg[q].lines;
-            }
-        }
-    };
-
     bool pending_wait = false;                         // the last cluster barrier was arrived at but not yet waited for
     for (int crop = cluster; crop < a.n; crop += a.nclusters) {
         stamp(0);
+        if (a.timing != nullptr && blockIdx.x == 0 && tid == 0) a.timing[92] = clock64();      // shader cycles
         int cur = 0;                                   // XB[cur] = input of the current block (bi > 0)
         // crop -> its row in the block-6 output: lanes of the layer-wise front half are contiguous per lane
         size_t xoff = 0;
@@ -363,10 +272,18 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 if (l < a.nlanes && crop >= a.lane_start[l]) ls = a.lane_start[l];
             xoff = size_t(ls) * a.lane_stride + size_t(crop - ls) * a.x_in_stride;
         }
-        touch_block(0);
-        touch_retire(touch);
         for (int bi = 0; bi < a.nblk; ++bi) {
             const TrunkBlock B = a.blk[bi];            // uniform: scalar loads from the device table
+            const VT GLOBAL_AS* g_we = gptr<VT>(B.we);
+            const VT GLOBAL_AS* g_wp = gptr<VT>(B.wp);
+            const float GLOBAL_AS* g_be = gptr<float>(B.be);
+            const float GLOBAL_AS* g_wd = gptr<float>(B.wd);
+            const float GLOBAL_AS* g_bd = gptr<float>(B.bd);
+            const float GLOBAL_AS* g_w1t = gptr<float>(B.w1t);
+            const float GLOBAL_AS* g_b1 = gptr<float>(B.b1);
+            const float GLOBAL_AS* g_w2c = gptr<float>(B.w2c);
+            const float GLOBAL_AS* g_b2 = gptr<float>(B.b2);
+            const float GLOBAL_AS* g_bp = gptr<float>(B.bp);
             const bool detail = a.timing != nullptr && bi == a.timing_block;
             auto dstamp = [&](int i) {
                 if (detail && blockIdx.x == 0 && tid == 0) a.timing[128 + i] = wall_clock64();
@@ -378,21 +295,149 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
             int t0, tcnt;                              // own 32-channel tiles of the expanded tensor
             split_range(B.cexp >> 5, C, m, &t0, &tcnt);
             const int own_ch = tcnt * 32, c_own0 = t0 * 32;
+            const int sub_ch = B.sub_tiles * 32;       // channels of a full sub-chunk (the last one may be narrower)
+            const int EP = sub_ch * 4 + 16;            // pixel pitch of E (f32 + 16-byte pad)
+            const int nsub = (tcnt + B.sub_tiles - 1) / B.sub_tiles;
+            const bool dbuf = B.dbuf != 0;             // two E / taps / strip-sum buffers: expand(s+1) runs beside taps(s)
             unsigned char* X = smem;
-            unsigned char* E = smem + B.off_e;
-            float* s_dww = reinterpret_cast<float*>(smem + B.off_dww);
-            float* s_red = reinterpret_cast<float*>(smem + B.off_red);
             const int nstrip_i = (HWi + 31) >> 5, nstrip_o = (HWo + 31) >> 5;
+            const int nstrip_dw = B.h_out * (B.h_out / P);
+            const int ntap = B.k * B.k;
+            auto Ebuf = [&](int s) -> unsigned char* { return smem + B.off_e + (dbuf ? (s & 1) * B.e_bytes : 0); };
+            auto Wbuf = [&](int s) -> float* { return reinterpret_cast<float*>(smem + B.off_dww) + (dbuf ? (s & 1) * ntap * sub_ch : 0); };
+            auto Rbuf = [&](int s) -> float* { return reinterpret_cast<float*>(smem + B.off_red) + (dbuf ? (s & 1) * nstrip_dw * sub_ch : 0); };
+            auto sub_cc = [&](int s) -> int {           // channels of sub-chunk s
+                const int left = tcnt - s * B.sub_tiles;
+                return ((left < B.sub_tiles) ? left : B.sub_tiles) * 32;
+            };
             dstamp(0);
-            touch_block(bi + 1);                       // the NEXT block's weights start their way into L2 now
 
-            // ---- independent of the block input: biases of the own channels, sub-chunk 0 set-up (these
-            // loads and LDS writes fill the wait for the previous block's output) ----------------------
-            for (int c = tid; c < own_ch; c += TNT) {
-                s_be[c] = B.be[c_own0 + c];
-                s_bd[c] = B.bd[c_own0 + c];
+            // depthwise taps of sub-chunk s -> its LDS buffer, by lanes [t_lo, t_lo + t_n) (global -> registers
+            // first, LDS after: the loads of one call are all in flight together)
+            auto load_taps = [&](int s, int t_lo, int t_n) {
+                const int cc = sub_cc(s);
+                float* dst = Wbuf(s);
+                const float GLOBAL_AS* src = g_wd + c_own0 + s * sub_ch;
+                const int total = ntap * (cc / 4);                   // float4 units
+                for (int i0 = t_lo; i0 < total; i0 += 4 * t_n) {
+                    float4v wv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * t_n;
+                        const int tap = i / (cc / 4), c4 = i - tap * (cc / 4);
+                        wv[u] = (i < total) ? *reinterpret_cast<const float4v GLOBAL_AS*>(src + size_t(tap) * B.cexp + c4 * 4)
+                                            : float4v{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * t_n;
+                        const int tap = i / (cc / 4), c4 = i - tap * (cc / 4);
+                        if (i < total) *reinterpret_cast<float4v*>(dst + tap * sub_ch + c4 * 4) = wv[u];
+                    }
+                }
+            };
+            // expand (MFMA) of sub-chunk s -> E buffer, (strip, tile) tasks over waves [w_lo, w_lo + w_n)
+            auto expand_tasks = [&](int s, int w_lo, int w_n) {
+                const int ntile = sub_cc(s) / 32;
+                unsigned char* E = Ebuf(s);
+                for (int t = wave - w_lo; t < nstrip_i * ntile; t += w_n) {
+                    const int tile = t / nstrip_i, strip = t - tile * nstrip_i;
+                    const int p = strip * 32 + lm;
+                    const bool valid = p < HWi;
+                    const unsigned char* xrow = X + size_t(valid ? p : 0) * pin + g * V * SZ;
+                    float16v acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    const VT GLOBAL_AS* wf = g_we + size_t(t0 + s * B.sub_tiles + tile) * 64 + lane;
+                    const int wstride = B.nte * 64;
+                    gemm_task<T, 7>(
+                        acc, 0, B.kse, [&](int ks) -> VT { return wf[size_t(ks) * wstride]; },
+                        [&](int ks) -> VT {
+                            return valid ? *reinterpret_cast<const VT*>(xrow + size_t(ks) * 2 * V * SZ) : vec_zero<T>();
+                        });
+                    if (valid) {
+                        const int py = p / B.h_in, px = p - py * B.h_in;
+                        unsigned char* epix = E + size_t((py + B.pad) * EW + px + B.pad) * EP;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int nl = tile * 32 + 8 * qq + 4 * g;
+                            const float4v bv = *reinterpret_cast<const float4v*>(s_be + s * sub_ch + nl);
+                            float4v o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[r]);
+                            *reinterpret_cast<float4v*>(epix + nl * 4) = o;
+                        }
+                    }
+                }
+            };
+            auto taps_tasks = [&](int s, int t_lo, int t_n) {
+                const int cc = sub_cc(s);
+                const int dcol0 = s * sub_ch;
+                if (B.vc == 2) {
+                    if (B.k == 3) dw_tasks<T, 3, 1, 2>(Ebuf(s), EW, EP, DB, own_ch, dcol0, Wbuf(s), sub_ch, s_bd + dcol0, Rbuf(s), B.h_out, cc, t_lo, t_n);
+                    else if (B.s == 1) dw_tasks<T, 5, 1, 2>(Ebuf(s), EW, EP, DB, own_ch, dcol0, Wbuf(s), sub_ch, s_bd + dcol0, Rbuf(s), B.h_out, cc, t_lo, t_n);
+                    else dw_tasks<T, 5, 2, 2>(Ebuf(s), EW, EP, DB, own_ch, dcol0, Wbuf(s), sub_ch, s_bd + dcol0, Rbuf(s), B.h_out, cc, t_lo, t_n);
+                } else {
+                    if (B.k == 3) dw_tasks<T, 3, 1, 4>(Ebuf(s), EW, EP, DB, own_ch, dcol0, Wbuf(s), sub_ch, s_bd + dcol0, Rbuf(s), B.h_out, cc, t_lo, t_n);
+                    else if (B.s == 1) dw_tasks<T, 5, 1, 4>(Ebuf(s), EW, EP, DB, own_ch, dcol0, Wbuf(s), sub_ch, s_bd + dcol0, Rbuf(s), B.h_out, cc, t_lo, t_n);
+                    else dw_tasks<T, 5, 2, 4>(Ebuf(s), EW, EP, DB, own_ch, dcol0, Wbuf(s), sub_ch, s_bd + dcol0, Rbuf(s), B.h_out, cc, t_lo, t_n);
+                }
+            };
+            // channel sums of sub-chunk s over its strips, fixed order, by lanes t_lo .. (one lane per channel)
+            auto colsum = [&](int s, int t_lo) {
+                const int cc = sub_cc(s);
+                const float* red = Rbuf(s);
+                const int c = tid - t_lo;
+                if (c >= 0 && c < cc) {
+                    float t = 0.0f;
+                    for (int q0 = 0; q0 < nstrip_dw; q0 += 14) {
+                        float v[14];
+#pragma unroll
+                        for (int q = 0; q < 14; ++q) v[q] = (q0 + q < nstrip_dw) ? red[(q0 + q) * sub_ch + c] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 14; ++q)
+                            if (q0 + q < nstrip_dw) t += v[q];
+                    }
+                    s_sum[s * sub_ch + c] = t;
+                }
+            };
+            // depthwise taps of sub-chunk s in two halves: request (registers), commit (LDS) -- one float4 per lane
+            auto taps_request = [&](int s, int t, int t_n, float4v& r0, float4v& r1) {
+                const int cc = sub_cc(s);
+                const float GLOBAL_AS* src = g_wd + c_own0 + s * sub_ch;
+                const int total = ntap * (cc / 4);
+                const int i0 = t, i1 = t + t_n;
+                if (i0 < total) r0 = *reinterpret_cast<const float4v GLOBAL_AS*>(src + size_t(i0 / (cc / 4)) * B.cexp + (i0 % (cc / 4)) * 4);
+                if (i1 < total) r1 = *reinterpret_cast<const float4v GLOBAL_AS*>(src + size_t(i1 / (cc / 4)) * B.cexp + (i1 % (cc / 4)) * 4);
+            };
+            auto taps_commit = [&](int s, int t, int t_n, const float4v& r0, const float4v& r1) {
+                const int cc = sub_cc(s);
+                float* dst = Wbuf(s);
+                const int total = ntap * (cc / 4);
+                const int i0 = t, i1 = t + t_n;
+                if (i0 < total) *reinterpret_cast<float4v*>(dst + (i0 / (cc / 4)) * sub_ch + (i0 % (cc / 4)) * 4) = r0;
+                if (i1 < total) *reinterpret_cast<float4v*>(dst + (i1 / (cc / 4)) * sub_ch + (i1 % (cc / 4)) * 4) = r1;
+                if (total > 2 * t_n) {                 // (wide sub-chunks only)
+                    const float GLOBAL_AS* src = g_wd + c_own0 + s * sub_ch;
+                    for (int i = t + 2 * t_n; i < total; i += t_n)
+                        *reinterpret_cast<float4v*>(dst + (i / (cc / 4)) * sub_ch + (i % (cc / 4)) * 4) =
+                            *reinterpret_cast<const float4v GLOBAL_AS*>(src + size_t(i / (cc / 4)) * B.cexp + (i % (cc / 4)) * 4);
+                }
+            };
+
+            // ---- independent of the block input (fills the wait for the previous block's output): biases of
+            // the own channels, zeroed E buffers (the halo is TF 'SAME' padding of the EXPANDED tensor; every
+            // sub-chunk rewrites the interior), depthwise taps of sub-chunk 0
+            {
+                for (int c = tid; c < own_ch; c += TNT) {
+                    s_be[c] = g_be[c_own0 + c];
+                    s_bd[c] = g_bd[c_own0 + c];
+                }
+                const int ez = (dbuf ? 2 : 1) * B.e_bytes / 16;
+                float4v* e4 = reinterpret_cast<float4v*>(smem + B.off_e);
+                for (int i = tid; i < ez; i += TNT) e4[i] = float4v{0.f, 0.f, 0.f, 0.f};
+                load_taps(0, tid, TNT);
             }
-            setup_chunk(B, c_own0, ((tcnt < B.sub_tiles) ? tcnt : B.sub_tiles) * 32);
             dstamp(1);
             if (pending_wait) {
                 cluster_wait(counter, phase, err);     // ---- exchange 3 of the previous block: its output
@@ -405,15 +450,15 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 const int vpr = B.cin * SZ / 16;
                 const int total = HWi * vpr;
                 const Buf xb(xsrc, unsigned(HWi * B.cin * SZ));
-                for (int i0 = tid; i0 < total; i0 += 4 * TNT) {
-                    u32x4 xv[4];
+                for (int i0 = tid; i0 < total; i0 += 3 * TNT) {
+                    u32x4 xv[3];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 3; ++u) {
                         const int i = i0 + u * TNT;
                         xv[u] = xb.ld16(unsigned(i < total ? i : 0) * 16u);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 3; ++u) {
                         const int i = i0 + u * TNT;
                         if (i < total) {
                             const int r = i / vpr, v = i - r * vpr;
@@ -422,136 +467,115 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             stamp(1 + bi * 8 + 0);
             dstamp(3);
 
             // ================= phase 1: expand (MFMA) -> E, depthwise -> D, channel sums ==========
-            for (int ts = 0; ts < tcnt; ts += B.sub_tiles) {
-                const int ntile = (tcnt - ts < B.sub_tiles) ? (tcnt - ts) : B.sub_tiles;
-                const int ccur = ntile * 32;
-                const int c0 = c_own0 + ts * 32;       // first expanded channel of this sub-chunk
-                const int EP = ccur * SZ + 16;
-                if (ts > 0) {
-                    setup_chunk(B, c0, ccur);
-                    __syncthreads();
-                }
-                for (int t = wave; t < nstrip_i * ntile; t += TNW) {
-                    const int tile = t / nstrip_i, strip = t - tile * nstrip_i;
-                    const int p = strip * 32 + lm;
-                    const bool valid = p < HWi;
-                    const unsigned char* xrow = X + size_t(valid ? p : 0) * pin + g * V * SZ;
-                    float16v acc;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    const VT* wf = reinterpret_cast<const VT*>(B.we) + size_t(t0 + ts + tile) * 64 + lane;
-                    const int wstride = B.nte * 64;
-                    gemm_task<T, 8>(
-                        acc, 0, B.kse, [&](int ks) -> VT { return wf[size_t(ks) * wstride]; },
-                        [&](int ks) -> VT {
-                            return valid ? *reinterpret_cast<const VT*>(xrow + size_t(ks) * 2 * V * SZ) : vec_zero<T>();
-                        });
-                    if (valid) {
-                        const int py = p / B.h_in, px = p - py * B.h_in;
-                        unsigned char* epix = E + size_t((py + B.pad) * EW + px + B.pad) * EP;
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) {
-                            const int nl = tile * 32 + 8 * qq + 4 * g;
-                            const float4v bv = *reinterpret_cast<const float4v*>(s_be + ts * 32 + nl);
-                            OT o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = T(swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[r]));
-                            *reinterpret_cast<OT*>(epix + nl * SZ) = o;
+            if (dbuf) {
+                // software pipeline over the sub-chunks, one barrier per step: waves 0..7 run the depthwise
+                // lane-tasks of sub-chunk s while waves 8..15 expand sub-chunk s + 1 into the other E buffer
+                // (one (strip, tile) task each), fetch its taps and fold the strip sums of s - 1: matrix cores,
+                // VALU and LDS of the CU all stay busy and no wave runs more than one task per step
+                expand_tasks(0, 0, TNW);
+                lds_barrier();
+                dstamp(4);
+                for (int s = 0; s < nsub; ++s) {
+                    if (wave < RW) {
+                        taps_tasks(s, tid, RT);
+                    } else {
+                        float4v tr0 = {0.f, 0.f, 0.f, 0.f}, tr1 = tr0;
+                        const bool more = s + 1 < nsub;
+                        if (more) {
+                            taps_request(s + 1, tid - RT, RT, tr0, tr1);
+                            expand_tasks(s + 1, RW, RW);
+                            taps_commit(s + 1, tid - RT, RT, tr0, tr1);
                         }
+                        if (s > 0) colsum(s - 1, TNT - ((sub_ch + 63) & ~63));      // (lanes of the last waves: fewest expand tasks)
                     }
+                    lds_barrier();
+                    if (s < 8) dstamp(5 + s);
                 }
-                __syncthreads();
-                if (ts == 0) stamp(1 + bi * 8 + 1);
-                dstamp(ts == 0 ? 4 : 8);
-                const int dcol0 = ts * 32;
-                if (B.k == 3) dw_chunk<T, 3, 1, TNT>(E, EW, EP, DB, own_ch, dcol0, s_dww, s_bd + dcol0, s_red, B.h_out, ccur, tid);
-                else if (B.s == 1) dw_chunk<T, 5, 1, TNT>(E, EW, EP, DB, own_ch, dcol0, s_dww, s_bd + dcol0, s_red, B.h_out, ccur, tid);
-                else dw_chunk<T, 5, 2, TNT>(E, EW, EP, DB, own_ch, dcol0, s_dww, s_bd + dcol0, s_red, B.h_out, ccur, tid);
-                __syncthreads();
-                if (ts == 0) stamp(1 + bi * 8 + 2);
-                dstamp(ts == 0 ? 5 : 9);
-                if (tid < ccur) {
-                    const int nstrip = B.h_out * (B.h_out / P);
-                    float t = 0.0f;
-                    for (int s = 0; s < nstrip; ++s) t += s_red[s * ccur + tid];
-                    s_sum[dcol0 + tid] = t;
+                colsum(nsub - 1, 0);
+            } else {
+                for (int s = 0; s < nsub; ++s) {
+                    if (s > 0) {                       // E: zero again (single buffer), park the taps
+                        float4v* e4 = reinterpret_cast<float4v*>(smem + B.off_e);
+                        for (int i = tid; i < B.e_bytes / 16; i += TNT) e4[i] = float4v{0.f, 0.f, 0.f, 0.f};
+                        load_taps(s, tid, TNT);
+                        lds_barrier();
+                    }
+                    expand_tasks(s, 0, TNW);
+                    lds_barrier();
+                    taps_tasks(s, tid, TNT);
+                    lds_barrier();
+                    colsum(s, 0);
+                    if (s < 4) dstamp(4 + s);
+                    lds_barrier();
                 }
-                __syncthreads();                       // s_red / E / s_dww are rewritten by the next sub-chunk
-                dstamp(ts == 0 ? 6 : 10);
             }
+            // reduce-conv rows of this lane for the squeeze-excite partial: requested before the last barrier
+            // wave w owns outputs j = w, w + TNW, ..
+            constexpr int JR = 64 / TNW;               // R <= 64
+            constexpr int CU4 = 5;                     // own channels per lane: <= 5 (own_ch <= 320), else looped
+            float w1r[JR][CU4];
+#pragma unroll
+            for (int jj = 0; jj < JR; ++jj) {
+                const int j = wave + TNW * jj;
+                const float GLOBAL_AS* wrow = g_w1t + size_t(j < B.r ? j : 0) * B.cexp + c_own0;
+#pragma unroll
+                for (int u = 0; u < CU4; ++u) {
+                    const int c = lane + 64 * u;
+                    w1r[jj][u] = (j < B.r && c < own_ch) ? wrow[c] : 0.f;
+                }
+            }
+            lds_barrier();
             stamp(1 + bi * 8 + 3);
+            dstamp(13);
 
             // ================= squeeze-excite, first half: own share of the reduce conv =========
-            // wave w owns outputs j = w, w + TNW, ..; all its loads of the reduce kernel are issued first
             {
                 float* rb = RBase + size_t(m) * 64;
-                constexpr int JR = 64 / TNW;           // R <= 64
-                float p4[JR][4];
-#pragma unroll
-                for (int jj = 0; jj < JR; ++jj)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) p4[jj][u] = 0.f;
-                for (int cb = lane; cb < own_ch; cb += 256) {
-                    float wv[JR][4];
-#pragma unroll
-                    for (int jj = 0; jj < JR; ++jj) {
-                        const int j = wave + TNW * jj;
-                        const float* wrow = B.w1t + size_t(j < B.r ? j : 0) * B.cexp + c_own0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int c = cb + 64 * u;
-                            wv[jj][u] = (j < B.r && c < own_ch) ? wrow[c] : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JR; ++jj)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int c = cb + 64 * u;
-                            if (c < own_ch) p4[jj][u] = fmaf(s_sum[c], wv[jj][u], p4[jj][u]);
-                        }
-                }
 #pragma unroll
                 for (int jj = 0; jj < JR; ++jj) {
                     const int j = wave + TNW * jj;
-                    float t = (p4[jj][0] + p4[jj][1]) + (p4[jj][2] + p4[jj][3]);
+                    float p4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < CU4; ++u) {
+                        const int c = lane + 64 * u;
+                        if (c < own_ch) p4[u & 3] = fmaf(s_sum[c], w1r[jj][u], p4[u & 3]);
+                    }
+                    if (j < B.r) {
+                        const float GLOBAL_AS* wrow = g_w1t + size_t(j) * B.cexp + c_own0;
+                        for (int c = lane + 64 * CU4; c < own_ch; c += 64) p4[0] = fmaf(s_sum[c], wrow[c], p4[0]);   // (small clusters)
+                    }
+                    float t = (p4[0] + p4[1]) + (p4[2] + p4[3]);
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
                     if (lane == 0 && j < B.r) st_sc1_f32(rb + j, t);
                 }
             }
-            dstamp(11);
-            touch_retire(touch);
+            dstamp(14);
             phase += unsigned(C);
             cluster_arrive(counter);                   // ---- exchange 1: SE partial vectors (+ own D stores drained)
-            dstamp(12);
+            dstamp(15);
 
-            // ---- while the other members arrive: everything of the second half that does not depend on them
+            // ---- while the other members arrive: everything of the second half that does not depend on them:
+            // the own k-steps of the project weights, the own depthwise output and the lane's share of the
+            // excite kernel are requested now and consumed after the wait
             unsigned char* Dg = smem;                  // X and E are dead from here on
             const int pd = own_ch * SZ + 16;
             const int ks0 = t0 * KPT, ks1 = (t0 + tcnt) * KPT;
-            VT* Wl = reinterpret_cast<VT*>(smem + align16(HWo * pd));       // project weights of the own k-steps
-            if (B.wp_lds) {
-                const VT* wsrc = reinterpret_cast<const VT*>(B.wp) + size_t(ks0) * B.ntp * 64;
-                const int total = (ks1 - ks0) * B.ntp * 64;
-                for (int i0 = tid; i0 < total; i0 += 4 * TNT) {
-                    VT wv[4];
+            VT* Wl = reinterpret_cast<VT*>(smem + align16(HWo * pd));       // gated project weights of the own k-steps
+            constexpr int WR = 7;
+            const int wtotal = B.wp_lds ? (ks1 - ks0) * B.ntp * 64 : 0;
+            VT wreg[WR];
+            {
+                const VT GLOBAL_AS* wsrc = g_wp + size_t(ks0) * B.ntp * 64;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) wv[u] = (i0 + u * TNT < total) ? wsrc[i0 + u * TNT] : vec_zero<T>();
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u * TNT < total) Wl[i0 + u * TNT] = wv[u];
-                }
+                for (int u = 0; u < WR; ++u) wreg[u] = (tid + u * TNT < wtotal) ? wsrc[tid + u * TNT] : vec_zero<T>();
             }
-            dstamp(13);
-            // own D back from scratch (first DR vectors per lane stay in flight across the wait) and this
-            // lane's excite row
-            constexpr int DR = 6;
+            constexpr int DR = 4;
             const int vprd = own_ch * SZ / 16;
             const int dtotal = HWo * vprd;
             const Buf db(DB, unsigned(HWo * own_ch * SZ));
@@ -561,21 +585,23 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 const int i = tid + u * TNT;
                 dreg[u] = db.ld16(unsigned(i < dtotal ? i : 0) * 16u);
             }
-            constexpr int RPV = 12;                    // RP <= 48
-            float4v w2r[RPV];
+            // excite: two lanes per own channel, lane h takes the float4 pieces q = h, h + 2, .. of the row
+            constexpr int GV = 6;                      // RP <= 48: 12 float4 pieces per row
+            const int gch = tid >> 1, gh = tid & 1;
+            float4v w2r[GV];
             float b2r = 0.f;
             {
-                const int c = (tid < own_ch) ? tid : 0;
-                const float4v* wrow = reinterpret_cast<const float4v*>(B.w2c + size_t(c_own0 + c) * B.rp);
+                const int c = (gch < own_ch) ? gch : 0;
+                const float4v GLOBAL_AS* wrow = reinterpret_cast<const float4v GLOBAL_AS*>(g_w2c + size_t(c_own0 + c) * B.rp);
 #pragma unroll
-                for (int j = 0; j < RPV; ++j) w2r[j] = (4 * j < B.rp) ? wrow[j] : float4v{0.f, 0.f, 0.f, 0.f};
-                b2r = B.b2[c_own0 + c];
+                for (int j = 0; j < GV; ++j) w2r[j] = (4 * (2 * j + gh) < B.rp) ? wrow[2 * j + gh] : float4v{0.f, 0.f, 0.f, 0.f};
+                b2r = g_b2[c_own0 + c];
             }
-            const float b1r = (tid < B.r) ? B.b1[tid] : 0.f;
-            dstamp(14);
+            const float b1r = (tid < B.r) ? g_b1[tid] : 0.f;
+            dstamp(16);
             cluster_wait(counter, phase, err);
             stamp(1 + bi * 8 + 4);
-            dstamp(15);
+            dstamp(17);
 
             // ================= squeeze-excite, second half: gate of the own channels =============
             if (tid < 64) {
@@ -591,46 +617,51 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 }
                 s_r[tid] = t;                          // zero beyond R (the excite rows are zero-padded to RP)
             }
-            __syncthreads();
-            dstamp(16);
-            for (int c = tid; c < own_ch; c += TNT) {
-                float t0a, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-                if (c == tid) {
-                    t0a = b2r;
+            lds_barrier();
+            dstamp(18);
+            for (int c = gch; c < own_ch; c += TNT / 2) {
+                float t0a = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+                float bias2 = b2r;
+                if (c == gch) {
 #pragma unroll
-                    for (int j = 0; j < RPV; ++j) {
-                        if (4 * j < B.rp) {
-                            t0a = fmaf(s_r[4 * j], w2r[j][0], t0a);
-                            t1 = fmaf(s_r[4 * j + 1], w2r[j][1], t1);
-                            t2 = fmaf(s_r[4 * j + 2], w2r[j][2], t2);
-                            t3 = fmaf(s_r[4 * j + 3], w2r[j][3], t3);
+                    for (int j = 0; j < GV; ++j) {
+                        const int q = 2 * j + gh;
+                        if (4 * q < B.rp) {
+                            t0a = fmaf(s_r[4 * q], w2r[j][0], t0a);
+                            t1 = fmaf(s_r[4 * q + 1], w2r[j][1], t1);
+                            t2 = fmaf(s_r[4 * q + 2], w2r[j][2], t2);
+                            t3 = fmaf(s_r[4 * q + 3], w2r[j][3], t3);
                         }
                     }
-                } else {                               // (own_ch > 1024: small clusters only)
-                    const float4v* wrow = reinterpret_cast<const float4v*>(B.w2c + size_t(c_own0 + c) * B.rp);
-                    t0a = B.b2[c_own0 + c];
-                    for (int j = 0; j < B.rp; j += 4) {
-                        const float4v wv = wrow[j >> 2];
-                        t0a = fmaf(s_r[j], wv[0], t0a);
-                        t1 = fmaf(s_r[j + 1], wv[1], t1);
-                        t2 = fmaf(s_r[j + 2], wv[2], t2);
-                        t3 = fmaf(s_r[j + 3], wv[3], t3);
+                } else {                               // (own_ch > 512: small clusters only)
+                    const float4v GLOBAL_AS* wrow = reinterpret_cast<const float4v GLOBAL_AS*>(g_w2c + size_t(c_own0 + c) * B.rp);
+                    bias2 = g_b2[c_own0 + c];
+                    for (int q = gh; 4 * q < B.rp; q += 2) {
+                        const float4v wv = wrow[q];
+                        t0a = fmaf(s_r[4 * q], wv[0], t0a);
+                        t1 = fmaf(s_r[4 * q + 1], wv[1], t1);
+                        t2 = fmaf(s_r[4 * q + 2], wv[2], t2);
+                        t3 = fmaf(s_r[4 * q + 3], wv[3], t3);
                     }
                 }
-                s_gate[c] = sigmoid_f<true>((t0a + t1) + (t2 + t3));
+                const float mine = (t0a + t1) + (t2 + t3);
+                const float other = __shfl_xor(mine, 1, 64);
+                const float tot = gh ? (other + mine) : (mine + other);          // (even pieces) + (odd pieces)
+                if (gh == 0) s_gate[c] = T(sigmoid_f<true>(bias2 + tot));
             }
-            __syncthreads();
-            dstamp(17);
+            lds_barrier();
+            dstamp(19);
 
-            // ================= D * gate into LDS (B operand of the project GEMM) ==================
+            // ================= project operands into LDS: D (own channels) and gate * W (own k-steps) ==
+            // the gate scales the K dimension of the product, so it is folded into the weight fragments
+            // (one rounding to the activation type, as the activation * gate product had before)
             {
+                const bool gate_w = B.wp_lds != 0;
                 auto put = [&](int i, u32x4 raw) {
                     const int r = i / vprd, v = i - r * vprd;
-                    float f[V];
-                    vec_to_float<T>(as_vec<T>(raw), f);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) f[e] *= s_gate[v * V + e];
-                    *reinterpret_cast<VT*>(Dg + size_t(r) * pd + v * 16) = float_to_vec<T>(f);
+                    VT dv = as_vec<T>(raw);
+                    if (!gate_w) dv = dv * *reinterpret_cast<const VT*>(s_gate + v * V);
+                    *reinterpret_cast<VT*>(Dg + size_t(r) * pd + v * 16) = dv;
                 };
 #pragma unroll
                 for (int u = 0; u < DR; ++u)
@@ -643,10 +674,23 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                     for (int u = 0; u < 4; ++u)
                         if (i0 + u * TNT < dtotal) put(i0 + u * TNT, dv[u]);
                 }
+                if (gate_w) {
+                    auto putw = [&](int i, VT wv) {
+                        // fragment i = (k-step, tile, lane): its V weights sit at k = ks * 2V + (lane >> 5) * V + e
+                        const int ksl = i / (B.ntp * 64);
+                        const int kl = ksl * 2 * V + ((i >> 5) & 1) * V;
+                        Wl[i] = wv * *reinterpret_cast<const VT*>(s_gate + kl);
+                    };
+#pragma unroll
+                    for (int u = 0; u < WR; ++u)
+                        if (tid + u * TNT < wtotal) putw(tid + u * TNT, wreg[u]);
+                    const VT GLOBAL_AS* wsrc = g_wp + size_t(ks0) * B.ntp * 64;
+                    for (int i = tid + WR * TNT; i < wtotal; i += TNT) putw(i, wsrc[i]);
+                }
             }
-            __syncthreads();
+            lds_barrier();
             stamp(1 + bi * 8 + 5);
-            dstamp(18);
+            dstamp(20);
 
             // ================= project (MFMA), K = own channels -> partial [HWo][Cout] f32 ========
             {
@@ -666,11 +710,11 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                     if (B.wp_lds) {
                         const VT* wl = Wl + size_t(tile) * 64 + lane;
                         const int wstride = B.ntp * 64;
-                        gemm_task<T, 4>(acc, ks0, ks1, [&](int ks) -> VT { return wl[size_t(ks - ks0) * wstride]; }, load_d);
+                        gemm_task<T, 6>(acc, ks0, ks1, [&](int ks) -> VT { return wl[size_t(ks - ks0) * wstride]; }, load_d);
                     } else {
-                        const VT* wf = reinterpret_cast<const VT*>(B.wp) + size_t(tile) * 64 + lane;
+                        const VT GLOBAL_AS* wf = g_wp + size_t(tile) * 64 + lane;
                         const int wstride = B.ntp * 64;
-                        gemm_task<T, 8>(acc, ks0, ks1, [&](int ks) -> VT { return wf[size_t(ks) * wstride]; }, load_d);
+                        gemm_task<T, 6>(acc, ks0, ks1, [&](int ks) -> VT { return wf[size_t(ks) * wstride]; }, load_d);
                     }
                     if (valid) {
 #pragma unroll
@@ -688,10 +732,10 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                     }
                 }
             }
-            dstamp(19);
+            dstamp(21);
             phase += unsigned(C);
             cluster_arrive(counter);                   // ---- exchange 2: project partials
-            dstamp(20);
+            dstamp(22);
 
             // ================= reduce own rows: bias + partials in member order (+ skip) -> x_out ==
             {
@@ -703,7 +747,6 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 const Buf pall(PBase, unsigned(size_t(C) * a.pmax * 4));
                 const Buf xs(xsrc, unsigned(HWi * B.cin * SZ));
                 const Buf xb(xo, unsigned(HWo * B.cout * SZ));
-                // bias and skip of this lane's first unit do not depend on the partials: loaded before the wait
                 auto load_skip = [&](int u) -> OT {
                     OT rv;
                     if constexpr (SZ == 2) {
@@ -715,68 +758,91 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                     }
                     return rv;
                 };
-                OT skip0;
+                // bias and skip of this lane's first units do not depend on the partials: loaded before the wait
+                constexpr int RU = 2;
+                OT skip0[RU];
+                float4v bias0[RU];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) skip0[r] = T(0);
-                float4v bias0 = {0.f, 0.f, 0.f, 0.f};
-                if (tid < ucnt) {
-                    bias0 = *reinterpret_cast<const float4v*>(B.bp + ((u0 + tid) % upr) * 4);
-                    if (B.has_skip) skip0 = load_skip(u0 + tid);
+                for (int q = 0; q < RU; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) skip0[q][r] = T(0);
+                    bias0[q] = float4v{0.f, 0.f, 0.f, 0.f};
+                    const int i = tid + q * TNT;
+                    if (i < ucnt) {
+                        bias0[q] = *reinterpret_cast<const float4v GLOBAL_AS*>(g_bp + ((u0 + i) % upr) * 4);
+                        if (B.has_skip) skip0[q] = load_skip(u0 + i);
+                    }
                 }
                 cluster_wait(counter, phase, err);
                 stamp(1 + bi * 8 + 6);
-                dstamp(21);
-                for (int i = tid; i < ucnt; i += TNT) {
-                    const int u = u0 + i;
-                    float4v bv = bias0;
-                    OT rv = skip0;
-                    if (i != tid) {
-                        bv = *reinterpret_cast<const float4v*>(B.bp + (u % upr) * 4);
-                        if (B.has_skip) rv = load_skip(u);
-                    }
-                    float y[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int j0 = 0; j0 < C; j0 += 4) {            // fixed member order, 4 loads in flight
-                        u32x4 raw[4];
+                dstamp(23);
+                for (int i0 = tid; i0 < ucnt; i0 += RU * TNT) {
+                    float y[RU][4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            raw[j] = pall.ld16(unsigned((size_t(j0 + j < C ? j0 + j : j0) * a.pmax + size_t(u) * 4) * 4));
+                    for (int q = 0; q < RU; ++q)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (j0 + j < C) {
-                                float4v pv;
-                                __builtin_memcpy(&pv, &raw[j], 16);
+                        for (int r = 0; r < 4; ++r) y[q][r] = 0.f;
+                    for (int j0 = 0; j0 < C; j0 += 4) {            // fixed member order, 4 x RU loads in flight
+                        u32x4 raw[RU][4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) y[r] += pv[r];
-                            }
+                        for (int q = 0; q < RU; ++q) {
+                            const int i = i0 + q * TNT;
+                            const int u = u0 + (i < ucnt ? i : 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                raw[q][j] = pall.ld16(unsigned((size_t(j0 + j < C ? j0 + j : j0) * a.pmax + size_t(u) * 4) * 4));
                         }
+#pragma unroll
+                        for (int q = 0; q < RU; ++q)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (j0 + j < C) {
+                                    float4v pv;
+                                    __builtin_memcpy(&pv, &raw[q][j], 16);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) y[q][r] += pv[r];
+                                }
+                            }
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] += bv[r];
-                    if (B.has_skip) {
+                    for (int q = 0; q < RU; ++q) {
+                        const int i = i0 + q * TNT;
+                        if (i >= ucnt) continue;
+                        const int u = u0 + i;
+                        float4v bv = bias0[q];
+                        OT rv = skip0[q];
+                        if (i0 != tid) {               // (more than RU units per lane: small clusters only)
+                            bv = *reinterpret_cast<const float4v GLOBAL_AS*>(g_bp + (u % upr) * 4);
+                            if (B.has_skip) rv = load_skip(u);
+                        }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] += float(rv[r]);
-                    }
-                    OT o;
+                        for (int r = 0; r < 4; ++r) y[q][r] += bv[r];
+                        if (B.has_skip) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = T(y[r]);
-                    if constexpr (SZ == 2) {
-                        unsigned long long w;
-                        __builtin_memcpy(&w, &o, 8);
-                        st_sc1_u64(xo + size_t(u) * 4, w);
-                    } else {
-                        u32x4 w;
-                        __builtin_memcpy(&w, &o, 16);
-                        xb.st16(unsigned(u) * 16u, w);
+                            for (int r = 0; r < 4; ++r) y[q][r] += float(rv[r]);
+                        }
+                        OT o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = T(y[q][r]);
+                        if constexpr (SZ == 2) {
+                            unsigned long long w;
+                            __builtin_memcpy(&w, &o, 8);
+                            st_sc1_u64(xo + size_t(u) * 4, w);
+                        } else {
+                            u32x4 w;
+                            __builtin_memcpy(&w, &o, 16);
+                            xb.st16(unsigned(u) * 16u, w);
+                        }
                     }
                 }
                 cur = nxt;
             }
-            dstamp(22);
+            dstamp(24);
             phase += unsigned(C);
             cluster_arrive(counter);                   // ---- exchange 3: block output (waited for by its consumer)
             pending_wait = true;
             stamp(1 + bi * 8 + 7);
-            dstamp(23);
+            dstamp(25);
         }
 
         const TrunkBlock L = a.blk[a.nblk - 1];
@@ -835,7 +901,7 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         stamp(88);
         {
             const int nstrip = (HWl + 31) >> 5;                                // 2
@@ -853,7 +919,7 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq)
                     bv[qq] = *reinterpret_cast<const float4v*>(a.bh + (ht0 * 32 + tile * 32 + 8 * qq + 4 * g));
-                gemm_task<T, 8>(
+                gemm_task<T, 6>(
                     acc, 0, a.ksh, [&](int ks) -> VT { return wf[size_t(ks) * wstride]; },
                     [&](int ks) -> VT {
                         return valid ? *reinterpret_cast<const VT*>(xrow + size_t(ks) * 2 * V * SZ) : vec_zero<T>();
@@ -870,13 +936,13 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             for (int c = tid; c < own_n; c += TNT) {
                 const float f = (s_fp[c] + s_fp[own_n + c]) * (1.0f / 49.0f);
                 s_feat[c] = f;
                 if (a.feat != nullptr) a.feat[size_t(crop) * FEAT + ht0 * 32 + c] = f;
             }
-            __syncthreads();
+            lds_barrier();
         }
         stamp(89);
         // ================= Dense 120|66|66 (whenet.py:11-13): partial over the own features ========
@@ -905,7 +971,7 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s_part[wave * 256 + lane * 4 + i] = acc[i];
             }
-            __syncthreads();
+            lds_barrier();
             if (tid < N_LOGITS) {
                 float t = 0.0f;
 #pragma unroll
@@ -932,7 +998,7 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
                 s_logit[tid] = t;
                 if (a.logits != nullptr) a.logits[size_t(crop) * N_LOGITS + tid] = t;
             }
-            __syncthreads();
+            lds_barrier();
             // ============= decode (utils.py:7-11, whenet.py:28-33): wave h <-> head h ==============
             if (wave < 3) {
                 const int lo = (wave == 0) ? 0 : (wave == 1 ? N_YAW : N_YAW + N_PITCH);
@@ -974,10 +1040,11 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
             }
         }
         stamp(91);
+        if (a.timing != nullptr && blockIdx.x == 0 && tid == 0) a.timing[93] = clock64();
         // LBase / XB of this crop may be overwritten by the next crop only after member 0 has read them:
         // member 0 reads LBase right after the exchange above, and every member's next write to LBase /
         // XB lies behind >= 2 further cluster exchanges that member 0 takes part in -- no extra barrier.
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -989,64 +1056,83 @@ __global__ __launch_bounds__(TNT) void whenet_trunk_kernel(TrunkArgs a) {
 namespace {
 
 constexpr int LDS_LIMIT = 160 * 1024;
-constexpr int FIXED_BYTES = (4 * 1152 + 64) * 4;
 
-template <typename T>
-int front_bytes(const TrunkBlock& b, int sub_tiles, int* off_e, int* off_dww, int* off_red) {
-    const int SZ = int(sizeof(T));
+inline int fixed_bytes(int own_cap) { return own_cap * 4 * 4 + 64 * 4; }     // s_sum, s_be, s_bd, s_gate + s_r
+
+// LDS bytes of the front phase of block b with sub-chunks of `sub` tiles, single / double buffered
+int front_bytes(const TrunkBlock& b, int SZ, int sub, bool dbuf, int* off_e, int* e_bytes, int* off_dww, int* off_red) {
     const int HWi = b.h_in * b.h_in;
     const int EW = (b.h_out - 1) * b.s + b.k;
-    const int ccur = sub_tiles * 32;
+    const int cc = sub * 32;
     const int nstrip = b.h_out * (b.h_out / P);
+    const int nb = dbuf ? 2 : 1;
     *off_e = align16(HWi * (b.cin * SZ + 16));
-    *off_dww = *off_e + align16(EW * EW * (ccur * SZ + 16));
-    *off_red = *off_dww + align16(b.k * b.k * ccur * 4);
-    return *off_red + align16(nstrip * ccur * 4);
+    *e_bytes = align16(EW * EW * (cc * 4 + 16));
+    *off_dww = *off_e + nb * *e_bytes;
+    *off_red = *off_dww + nb * align16(b.k * b.k * cc * 4);
+    return *off_red + nb * align16(nstrip * cc * 4);
 }
 
 }  // namespace
 
-// Fills the geometry-dependent fields of `blk` (sub_tiles, LDS offsets) for cluster size C and returns the
-// plan (LDS bytes, scratch layout).  Pure host logic.
+// Fills the geometry-dependent fields of `blk` (sub_tiles, buffering, LDS offsets) for cluster size C and
+// returns the plan (LDS bytes, scratch layout).  Pure host logic.
 TrunkPlan plan_trunk(TrunkBlock* blk, int nblk, int dtype, int C, int head_nth, int head_cin) {
     WHENET_REQUIRE(C >= 1 && C <= 16 && nblk >= 1, WHENET_EINVAL, "trunk: cluster size must be 1..16");
     const int SZ = dtype == WHENET_F16 ? 2 : 4;
     TrunkPlan p{};
     p.C = C;
-    int need = 0;
+    int need = 0, own_cap = 0;
     size_t xmax = 0, dmax = 0, pmax = 0;
+    for (int bi = 0; bi < nblk; ++bi) own_cap = std::max(own_cap, ((blk[bi].cexp / 32 + C - 1) / C) * 32);
+    const int FIXED = fixed_bytes(own_cap);
     for (int bi = 0; bi < nblk; ++bi) {
         TrunkBlock& b = blk[bi];
         WHENET_REQUIRE(b.cexp % 32 == 0 && b.cin % 8 == 0 && b.cout % 4 == 0 && b.h_out % P == 0 && b.r <= 64,
                        WHENET_EINVAL, "trunk: unsupported block geometry");
         const int tiles = b.cexp / 32;
         const int own_max = (tiles + C - 1) / C;
+        const int nstrip_i = (b.h_in * b.h_in + 31) / 32;
+        const int nstrip_dw = b.h_out * (b.h_out / P);
+        // Pipelined form (two buffers): 8 waves run depthwise lane-tasks (2 channels x 7 pixels per lane) while 8
+        // waves expand the next sub-chunk, one (strip, tile) task per wave.  Otherwise one buffer and all 16
+        // waves per phase.
         int best = 0;
-        for (int sub = own_max; sub >= 1; --sub) {
-            int oe, od, orr;
-            const int fb = dtype == WHENET_F16 ? front_bytes<half_t>(b, sub, &oe, &od, &orr)
-                                               : front_bytes<float>(b, sub, &oe, &od, &orr);
-            if (fb + FIXED_BYTES <= LDS_LIMIT) {
-                best = sub;
-                break;
+        bool best_dbuf = false;
+        for (int pass = 0; pass < 2 && best == 0; ++pass) {
+            const bool dbuf = pass == 0;
+            const int lanes = dbuf ? RT : TNT, waves = dbuf ? RW : TNW;
+            int want = std::min(lanes / (16 * nstrip_dw), waves / nstrip_i);      // 16 lane-tasks per tile per strip
+            want = std::max(1, std::min(want, own_max));
+            for (int sub = want; sub >= 1; --sub) {
+                int oe, eb, od, orr;
+                if (front_bytes(b, SZ, sub, dbuf, &oe, &eb, &od, &orr) + FIXED <= LDS_LIMIT) {
+                    best = sub;
+                    best_dbuf = dbuf;
+                    break;
+                }
             }
         }
-        WHENET_REQUIRE(best >= 1, WHENET_EINVAL, "trunk: block does not fit the LDS budget");
+        WHENET_REQUIRE(best >= 1, WHENET_EINVAL, "trunk: block does not fit the LDS budget (cluster too small?)");
         // balance the sub-chunks of the largest member: ceil(own / ceil(own / best))
         const int nsub = (own_max + best - 1) / best;
         b.sub_tiles = (own_max + nsub - 1) / nsub;
-        int oe, od, orr;
-        const int fb = dtype == WHENET_F16 ? front_bytes<half_t>(b, b.sub_tiles, &oe, &od, &orr)
-                                           : front_bytes<float>(b, b.sub_tiles, &oe, &od, &orr);
+        b.dbuf = best_dbuf ? 1 : 0;
+        b.vc = (b.sub_tiles * 16 * nstrip_dw <= (best_dbuf ? RT : TNT)) ? 2 : 4;      // 2 channels per lane while every lane-task finds a lane
+        int oe, eb, od, orr;
+        const int fb = front_bytes(b, SZ, b.sub_tiles, best_dbuf, &oe, &eb, &od, &orr);
         b.off_e = oe;
+        b.e_bytes = eb;
         b.off_dww = od;
         b.off_red = orr;
         const int HWo = b.h_out * b.h_out;
         int dg = align16(HWo * (own_max * 32 * SZ + 16));
-        // the own k-steps of the project weights are staged in LDS next to D * gate when they fit
+        WHENET_REQUIRE(dg + FIXED <= LDS_LIMIT, WHENET_EINVAL,
+                       "trunk: a member's depthwise output does not fit LDS (cluster too small)");
+        // the own k-steps of the project weights are staged in LDS (gate folded in) next to D when they fit
         const int kpt = 32 / (2 * (16 / SZ));
         const int wl = own_max * kpt * b.ntp * 1024;
-        b.wp_lds = (dg + wl + FIXED_BYTES <= LDS_LIMIT) ? 1 : 0;
+        b.wp_lds = (dg + wl + FIXED <= LDS_LIMIT) ? 1 : 0;
         if (b.wp_lds) dg += wl;
         need = std::max(need, std::max(fb, dg));
         xmax = std::max(xmax, std::max(size_t(b.h_in) * b.h_in * b.cin, size_t(HWo) * b.cout));
@@ -1055,11 +1141,12 @@ TrunkPlan plan_trunk(TrunkBlock* blk, int nblk, int dtype, int C, int head_nth, 
     }
     {   // head: X [49][cin] + strip partials + features + dense partials
         const int own_n = ((head_nth + C - 1) / C) * 32;
-        const int head = align16(49 * (head_cin * SZ + 16)) + (3 * own_n + MAXW * 256) * 4;
+        const int head = align16(49 * (head_cin * SZ + 16)) + (3 * own_n + TNW * 256) * 4;
         need = std::max(need, head);
     }
+    p.own_cap = own_cap;
     p.fixed_off = align16(need);
-    p.lds_bytes = size_t(p.fixed_off) + FIXED_BYTES;
+    p.lds_bytes = size_t(p.fixed_off) + FIXED;
     WHENET_REQUIRE(p.lds_bytes <= size_t(LDS_LIMIT), WHENET_EINVAL, "trunk: LDS budget exceeded");
     p.xmax = (xmax + 63) & ~size_t(63);
     p.dmax = (dmax + 63) & ~size_t(63);
@@ -1079,38 +1166,31 @@ TrunkPlan plan_trunk(TrunkBlock* blk, int nblk, int dtype, int C, int head_nth, 
     return p;
 }
 
-template <typename T, int TNT>
+template <typename T>
 void launch_trunk_t(const TrunkArgs& a, size_t lds_bytes, hipStream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {      // > 64 KiB of dynamic LDS needs the opt-in
-        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_trunk_kernel<T, TNT>),
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_trunk_kernel<T>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((whenet_trunk_kernel<T, TNT>), dim3(unsigned(a.nclusters * a.C)), dim3(TNT), lds_bytes, stream, a);
+    hipLaunchKernelGGL((whenet_trunk_kernel<T>), dim3(unsigned(a.nclusters * a.C)), dim3(TNT), lds_bytes, stream, a);
 }
 
-void launch_trunk(const TrunkArgs& a, size_t lds_bytes, int dtype, int threads, hipStream_t stream) {
+void launch_trunk(const TrunkArgs& a, size_t lds_bytes, int dtype, hipStream_t stream) {
     WHENET_REQUIRE(a.nblk >= 1 && a.n >= 1 && a.blk != nullptr && a.C >= 1 && a.nclusters >= 1, WHENET_EINVAL,
                    "trunk kernel: bad arguments");
-    WHENET_REQUIRE(threads == 512 || threads == 1024, WHENET_EINVAL, "trunk kernel: threads must be 512 or 1024");
     // the arrival counters (and error words) restart from zero on every launch / graph replay
     WHENET_HIP_CHECK(hipMemsetAsync(a.counters, 0, size_t(a.nclusters) * 16 * sizeof(unsigned), stream));
-    if (dtype == WHENET_F16) {
-        if (threads == 512) launch_trunk_t<half_t, 512>(a, lds_bytes, stream);
-        else launch_trunk_t<half_t, 1024>(a, lds_bytes, stream);
-    } else {
-        if (threads == 512) launch_trunk_t<float, 512>(a, lds_bytes, stream);
-        else launch_trunk_t<float, 1024>(a, lds_bytes, stream);
-    }
+    if (dtype == WHENET_F16) launch_trunk_t<half_t>(a, lds_bytes, stream);
+    else launch_trunk_t<float>(a, lds_bytes, stream);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
-std::string kernel_name_trunk(int dtype, int threads) {
-    return std::string("whenet_trunk_kernel<") + (dtype == WHENET_F16 ? "_Float16" : "float") + ", " +
-           std::to_string(threads) + ">";
+std::string kernel_name_trunk(int dtype) {
+    return std::string("whenet_trunk_kernel<") + (dtype == WHENET_F16 ? "_Float16" : "float") + ">";
 }
 
 }  // namespace whenet

@@ -72,8 +72,8 @@ def test_info(handle):
     i = handle.info()
     assert i.abi_version == _lib.ABI_VERSION
     assert (i.params_backbone, i.params_heads, i.n_tensors) == (4_049_564, 322_812, 315)
-    # stem, dw(b1), 5 front, 6 se, 6 project, trunk  (51 with option trunk=0: 15 front, 16 se, 16 project, head conv, heads)
-    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 20
+    # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads  (20 with option trunk=1: blocks 7..16 + head as one launch)
+    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 51
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
 
@@ -140,12 +140,13 @@ def test_trunk_kernel_head(handle, taps):
     assert np.abs(r["ypr"] - np.stack([y, p, rr], 1)).max() < (F32_DEG if handle.name == "f32" else F16_DEG)
 
 
-@pytest.mark.parametrize("c", [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize("c", [5, 8, 11, 16])
 def test_trunk_cluster_sizes(blob, golden, c):
     """Any cluster size gives the same network (the channel split and the order of the split-K partial
     sums change with it, nothing else): f32 within the parity bar for every C, incl. C = 1 (no exchange
     partner), C = 3 (uneven tile split) and C = 16 (members with a single 32-channel tile)."""
     with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
+        h.set_option("trunk", 1)
         h.set_option("trunk_c", c)
         crops = np.concatenate([golden["crops"], golden["crops"][::-1]])
         ypr, am, lg = h.forward(crops)
@@ -157,16 +158,20 @@ def test_trunk_cluster_sizes(blob, golden, c):
 
 
 def test_trunk_vs_layerwise(handle, golden):
-    """Same network, two schedules: the trunk launch and one launch per layer."""
+    """Same network, two schedules: one launch per layer (default) and the trunk launch (option)."""
     crops = golden["crops"]
-    ypr1, am1, lg1 = handle.forward(crops)
-    handle.set_option("trunk", 0)
+    ypr0, am0, lg0 = handle.forward(crops)
+    assert handle.info().n_kernels_per_forward == 51
+    handle.set_option("trunk", 1)
     try:
-        ypr0, am0, lg0 = handle.forward(crops)
-        assert handle.info().n_kernels_per_forward == 51
+        ypr1, am1, lg1 = handle.forward(crops)
+        assert handle.info().n_kernels_per_forward == 20
+        # with sub-batch lanes the layer-wise front half runs per lane and ONE trunk launch takes the whole batch
+        many = np.concatenate([crops] * 6)                       # 48 crops: 3 lanes of 16
+        y3, _, l3 = handle.forward(many)
+        assert np.array_equal(l3, np.concatenate([lg1] * 6))
     finally:
-        handle.set_option("trunk", 1)
-    assert handle.info().n_kernels_per_forward == 20
+        handle.set_option("trunk", 0)
     assert np.abs(lg1 - lg0).max() < (2e-3 if handle.name == "f32" else 0.6)
     exp = golden["expected"]["angles"]
     for ypr in (ypr0, ypr1):
@@ -177,12 +182,16 @@ def test_trunk_many_crops_per_cluster(handle):
     """More crops than clusters (each cluster loops over several crops, reusing its scratch and its
     monotonic arrival counter): bitwise the results of the crops run one batch at a time."""
     crops = np.concatenate([synth.scene_crops(100, seed=31), synth.noise_crops(60, seed=32)])    # 160 > 64 clusters
-    ypr, am, lg = handle.forward(crops)
-    for lo in (0, 64, 128):
-        y, a, l = handle.forward(crops[lo:lo + 64])
-        assert np.array_equal(l, lg[lo:lo + 64]) and np.array_equal(y, ypr[lo:lo + 64])
-    y1, _, l1 = handle.forward(crops[77:78])
-    assert np.array_equal(l1[0], lg[77])
+    handle.set_option("trunk", 1)
+    try:
+        ypr, am, lg = handle.forward(crops)
+        for lo in (0, 64, 128):
+            y, a, l = handle.forward(crops[lo:lo + 64])
+            assert np.array_equal(l, lg[lo:lo + 64]) and np.array_equal(y, ypr[lo:lo + 64])
+        y1, _, l1 = handle.forward(crops[77:78])
+        assert np.array_equal(l1[0], lg[77])
+    finally:
+        handle.set_option("trunk", 0)
 
 
 def test_decode_kernel(handle):

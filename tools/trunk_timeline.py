@@ -20,7 +20,7 @@ x = np.random.default_rng(0).normal(0, 1, (n, 14, 14, 80)).astype(np.float32)
 r = h.op_trunk(x)
 t = r["timing"].astype(np.int64)
 us = lambda a, b: (t[b] - t[a]) / 100.0
-print(f"dtype {dt} n={n} {' '.join(sys.argv[3:])}: total {us(0, 91):.1f} us")
+print(f"dtype {dt} n={n} {' '.join(sys.argv[3:])}: total {us(0, 91):.1f} us; shader clock {(t[93] - t[92]) / max(us(0, 91), 1e-9):.0f} MHz (clock64 ticks / wall us)")
 names = ("wait3+gather", "expand0", "dw0", "rest1", "se1+arrive+prefetch+wait1", "r+gate+stage", "project+arrive2+wait2", "reduce+arrive3")
 tot = {k: 0.0 for k in names}
 for bi in range(10):
@@ -34,11 +34,12 @@ print("cols: " + " | ".join(names))
 print("sum: " + " | ".join(f"{v:6.1f}" for v in tot.values()))
 print(f"head: wait+gather {us(1 + 9*8 + 7, 88):.1f} conv+GAP {us(88, 89):.1f} dense+sync {us(89, 90):.1f} decode {us(90, 91):.1f}")
 d = t[128:]
-dn = ["start", "bias+setup0", "wait3", "gather", "expand0", "taps0", "colsum0", "setup1", "expand1", "taps1", "colsum1",
-      "se1", "arrive1", "Wp->LDS", "D/w2c issue", "wait1", "r", "gate", "Dg", "project", "arrive2", "wait2", "reduce", "arrive3"]
+dn = ["start", "bias+zeroE+taps0", "wait3", "gather", "expand0", "it0", "it1", "it2", "it3", "it4", "it5", "it6", "it7",
+      "colsum+w1 issue", "se1", "arrive1", "issue Wp/D/w2c", "wait1", "r", "gate", "stage D,W*g", "project", "arrive2", "wait2",
+      "reduce", "arrive3"]
 prev = d[0]
 out = []
-for i in range(1, 24):
+for i in range(1, 26):
     if d[i] == 0:
         continue
     out.append(f"{dn[i]} {(d[i] - prev) / 100.0:.2f}")
