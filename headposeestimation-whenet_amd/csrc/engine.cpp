@@ -214,6 +214,10 @@ void Engine::set_option(const std::string& key, long value) {
         lanes_ = int(value);
         sync();
         drop_graphs();
+    } else if (key == "lane_graphs") {
+        lane_graphs_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "min_lane_crops") {
         WHENET_REQUIRE(value >= 1, WHENET_EINVAL, "min_lane_crops must be >= 1");
         min_lane_crops_ = int(value);
@@ -435,6 +439,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.w2c = b.se.w2c;
         a.b2 = b.se.b2;
         a.gate = v.gate;
+        a.gate_f16 = dtype_ == WHENET_F16;
         a.C = b.se.C;
         a.R = b.se.R;
         a.n = n;
@@ -451,6 +456,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.w2c = b.se.w2c;
         a.b2 = b.se.b2;
         a.gate = v.gate;
+        a.gate_f16 = dtype_ == WHENET_F16;
         a.C = b.se.C;
         a.R = b.se.R;
         a.n = n;
@@ -686,41 +692,70 @@ void Engine::enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_
     if (trunk_) enqueue_trunk(block6_out(view(0)), n, d_ypr, d_amax, d_logits, s, nullptr, lanes);
 }
 
+// Capture fn's launches on stream s into an executable graph (cached under key) and return it.
+template <typename F>
+hipGraphExec_t Engine::cached_graph(const GraphKey& key, hipStream_t s, F&& fn) {
+    auto it = graphs_.find(key);
+    if (it != graphs_.end()) return it->second;
+    if (graphs_.size() >= size_t(MAX_GRAPHS)) {
+        sync_streams(s);
+        drop_graphs();
+    }
+    hipGraph_t graph = nullptr;
+    WHENET_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    try {
+        fn();
+    } catch (...) {
+        (void)hipStreamEndCapture(s, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    WHENET_HIP_CHECK(hipStreamEndCapture(s, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) throw Error(WHENET_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    graphs_.emplace(key, exec);
+    return exec;
+}
+
 void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
     if (trunk_) ensure_trunk();          // allocations / uploads must not land inside a stream capture
     if (!use_graph_) {
         enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
         return;
     }
-    GraphKey key{n, d_in, d_ypr, d_amax, d_logits};
-    auto it = graphs_.find(key);
-    if (it == graphs_.end()) {
-        if (graphs_.size() >= size_t(MAX_GRAPHS)) {
-            WHENET_HIP_CHECK(hipStreamSynchronize(s));
-            drop_graphs();
+    int lanes = lanes_;
+    while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
+    if (lanes > 1) (void)lane_stream(lanes - 2);        // the lane streams exist before any capture starts
+    if (lane_graphs_ && lanes > 1 && !trunk_) {
+        // One graph PER LANE, each launched on its own stream: the chains then run as independent queues.
+        // (Branches of a single graph cost ~5 us per edge on this runtime, which eats the overlap.)
+        WHENET_HIP_CHECK(hipEventRecord(fork_ev_, s));
+        int off = 0;
+        for (int i = 0; i < lanes; ++i) {
+            const int cnt = n / lanes + (i < n % lanes ? 1 : 0);
+            hipStream_t st = (i == 0) ? s : lane_stream(i - 1);
+            const uint8_t* in_i = d_in + size_t(off) * IN_BYTES;
+            float* ypr_i = d_ypr + size_t(off) * 3;
+            int32_t* am_i = d_amax ? d_amax + size_t(off) * 3 : nullptr;
+            float* lg_i = d_logits ? d_logits + size_t(off) * N_LOGITS : nullptr;
+            hipGraphExec_t g = cached_graph(GraphKey{cnt, off, in_i, ypr_i, am_i, lg_i}, st, [&] {
+                enqueue_forward(view(off), in_i, cnt, ypr_i, am_i, lg_i, st, nullptr);
+            });
+            if (i > 0) WHENET_HIP_CHECK(hipStreamWaitEvent(st, fork_ev_, 0));
+            WHENET_HIP_CHECK(hipGraphLaunch(g, st));
+            if (i > 0) {
+                WHENET_HIP_CHECK(hipEventRecord(join_ev_[size_t(i - 1)], st));
+                WHENET_HIP_CHECK(hipStreamWaitEvent(s, join_ev_[size_t(i - 1)], 0));
+            }
+            off += cnt;
         }
-        hipGraph_t graph = nullptr;
-        {   // the lane streams this batch will fork into exist before the capture starts
-            int lanes = lanes_;
-            while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
-            if (lanes > 1) (void)lane_stream(lanes - 2);
-        }
-        WHENET_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        try {
-            enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
-        } catch (...) {
-            (void)hipStreamEndCapture(s, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            throw;
-        }
-        WHENET_HIP_CHECK(hipStreamEndCapture(s, &graph));
-        hipGraphExec_t exec = nullptr;
-        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) throw Error(WHENET_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        it = graphs_.emplace(key, exec).first;
+        return;
     }
-    WHENET_HIP_CHECK(hipGraphLaunch(it->second, s));
+    hipGraphExec_t g = cached_graph(GraphKey{n, -1, d_in, d_ypr, d_amax, d_logits}, s,
+                                    [&] { enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s); });
+    WHENET_HIP_CHECK(hipGraphLaunch(g, s));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,6 +811,11 @@ void Engine::forward_host_f32(const float* x, int n, float* ypr, int32_t* argmax
         WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
     check_trunk_error();
+}
+
+void Engine::sync_streams(hipStream_t s) {
+    WHENET_HIP_CHECK(hipStreamSynchronize(s));
+    for (hipStream_t st : lane_streams_) WHENET_HIP_CHECK(hipStreamSynchronize(st));
 }
 
 void Engine::sync() {
@@ -1077,8 +1117,7 @@ void Engine::op_block(int index, const float* in, int n, float* expand_out, floa
     if (sp.has_expand()) fetch(e_, exp_elems, expand_out);
     fetch(d_, dw_elems, dw_out);
     if (gate) {
-        WHENET_HIP_CHECK(hipMemcpyAsync(gate, gate_, N * sp.cexp() * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+        fetch(gate_, N * sp.cexp(), gate);         // (stored in the activation type: see se.hip)
     }
     fetch(x1_, out_elems, out);
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));

@@ -140,6 +140,10 @@ class Engine {
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
     hipStream_t lane_stream(int i);     // created on first use
+    using GraphKey = std::tuple<int, int, const void*, void*, void*, void*>;   // n, lane offset (-1: whole batch), buffers
+    template <typename F>
+    hipGraphExec_t cached_graph(const GraphKey& key, hipStream_t s, F&& fn);
+    void sync_streams(hipStream_t s);
     hipStream_t copy_stream();          // created on first use
     void ensure_slot_frame(Slot& s, size_t frame_bytes, int k);
     Slot* free_slot();
@@ -163,6 +167,7 @@ class Engine {
     int trunk_timing_block_ = 3;   // debug option "trunk_timing_block": block (0..9) with detailed phase stamps
     bool trunk_used_ = false;   // a trunk launch happened since the error words were last checked
     int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")
+    bool lane_graphs_ = false;  // one graph per lane on its own stream instead of one forked graph (option "lane_graphs")
     int min_lane_crops_ = 16;   // do not split below this many crops per chain
     std::vector<hipStream_t> lane_streams_;
     std::vector<hipEvent_t> join_ev_;
@@ -192,7 +197,6 @@ class Engine {
     float* o_logits_ = nullptr;
     size_t partial_per_crop_ = 0;
 
-    using GraphKey = std::tuple<int, const void*, void*, void*, void*>;
     std::map<GraphKey, hipGraphExec_t> graphs_;
 
     Slot slots_[WHENET_MAX_INFLIGHT];

@@ -58,8 +58,9 @@ struct SeArgs {
     const float* b1;       // [R]
     const float* w2c;      // [C][RP]  se_expand kernel, channel-major, R zero-padded to RP
     const float* b2;       // [C]
-    float* gate;           // [n][C]
+    void* gate;            // [n][C], float or (gate_f16) half: the type of the activations it multiplies
     int C, R, n;
+    int gate_f16 = 0;
 };
 void launch_se(const SeArgs& a, hipStream_t stream);
 // second half of the SEBlock when the producer (front.hip) already applied the reduce conv to its
@@ -71,8 +72,9 @@ struct SeExciteArgs {
     const float* b1;       // [R]
     const float* w2c;      // [C][RP]
     const float* b2;       // [C]
-    float* gate;           // [n][C]
+    void* gate;            // [n][C], float or (gate_f16) half
     int C, R, n;
+    int gate_f16 = 0;
 };
 void launch_se_excite(const SeExciteArgs& a, hipStream_t stream);
 int se_excite_split(int C);     // workgroups per crop
@@ -87,7 +89,7 @@ struct PwArgs {
     const void* wp;        // packed MFMA operand image (snapshot.h)
     const float* wdense;   // [K][N] (check kernel only)
     const float* bias;     // [N]
-    const float* gate;     // [n][K] or nullptr
+    const void* gate;      // [n][K] T or nullptr
     const void* res;       // [M][N] T or nullptr
     void* out;             // [M][N] T
     int M, K, N, KS, NTILES, HW, act;

@@ -34,154 +34,32 @@ namespace whenet {
 
 namespace {
 
-// NT  32-wide out-channel tiles per wave;  U  k-steps whose loads are issued together (software
-// pipelining: (1+NT)*U 16-byte loads in flight per lane before the first MFMA of the group);
-// SK  split-K factor: 1 = the 4 waves of a workgroup own 4 different 32-row strips,
-//     4 = the 4 waves split the k-steps of ONE strip (interleaved) and combine through LDS --
-//     used when there are too few rows to fill the chip (batch 1: M = 49..3136).
-template <typename T, int NT, int U, int SK, bool GATE, bool RES, int ACT>
-__global__ __launch_bounds__(256) void whenet_pw_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
-                                                        const float* __restrict__ bias,
-                                                        const float* __restrict__ gate, const T* __restrict__ res,
-                                                        T* __restrict__ out, int M, int K, int N, int KS, int NTILES,
-                                                        int HW, int MT, int NCH) {
+// Deep contractions (K >= 320: the project convs of blocks 7-16 and the head conv, all on 14x14 / 7x7
+// maps, i.e. few rows).  A workgroup owns B2*32 rows x B2*32 out-channels (B2 x B2 MFMA tiles per wave);
+// its 4 waves split the k-steps interleaved (wave p takes k-steps p, p+4, ..) and the four partial
+// accumulators are combined through LDS in wave order ((p0 + p1) + p2) + p3 -- for every batch size and
+// for both tile shapes, so a crop's bits do not depend on the batch it travels in.
+//   * B2 = 2 when that still launches enough workgroups to spread over the chip: every operand fragment
+//     then feeds two MFMAs (half the L2 -> CU traffic per flop of the 1 x 1 form);
+//   * the k-loop is software-pipelined in registers: the loads of the NEXT group of U k-steps (weights,
+//     activation rows, gate) are issued before the MFMAs of the current one, so a wave always has one
+//     group in flight while it multiplies (the kernel is latency-bound otherwise: few rows, deep K);
+//   * the SE gate multiplies the activation fragment as a T x T product (one packed multiply per two
+//     halfs; se.hip stores the gate in T);
+//   * the combine is spread over the 4 waves: wave p owns a quarter of the accumulators (B2 = 2: one of
+//     the four tiles; B2 = 1: four consecutive out-channels), receives the other three waves' share of it
+//     through LDS and runs bias / skip / store for it.
+template <typename T, int B2, bool GATE, bool RES, int ACT>
+__global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
+    const T* __restrict__ A, const T* __restrict__ Wp, const float* __restrict__ bias, const T* __restrict__ gate,
+    const T* __restrict__ res, T* __restrict__ out, int M, int K, int N, int KS, int NTILES, int HW, int MT, int NCH) {
     constexpr int V = Vec<T>::V;
     using VT = typename Vec<T>::type;
-    constexpr int STRIPS = (SK == 1) ? 4 : 1;
-
-    // XCD-aware decode of the 1-D grid (see header)
-    const int id = blockIdx.x;
-    const int q = id >> 3;
-    const int nch = q % NCH;
-    const int mt = (id & 7) + 8 * (q / NCH);
-    if (mt >= MT) return;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int m0 = (mt * STRIPS + (SK == 1 ? wave : 0)) * 32;
-    if (SK == 1 && m0 >= M) return;
-    const int kpart = (SK == 1) ? 0 : wave;
-    const int nt0 = nch * NT;
-    const int g = lane >> 5;
-    const int row = m0 + (lane & 31);
-    const bool rvalid = row < M;
-    const int rowc = rvalid ? row : (M - 1);
-
-    const T* ap = A + size_t(rowc) * K + g * V;
-    const float* gp = nullptr;
-    if constexpr (GATE) gp = gate + size_t(rowc / HW) * K + g * V;
-    const VT* wp = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64 + lane;
-
-    float16v acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    auto load_a = [&](int ks) -> VT {
-        VT a = vec_zero<T>();
-        if (rvalid && ks * 2 * V + g * V < K) {
-            a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
-            if constexpr (GATE) {
-                float f[V];
-                vec_to_float<T>(a, f);
-#pragma unroll
-                for (int i = 0; i < V; i += 4) {
-                    const float4v gv = *reinterpret_cast<const float4v*>(gp + ks * 2 * V + i);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f[i + j] *= gv[j];
-                }
-                a = float_to_vec<T>(f);
-            }
-        }
-        return a;
-    };
-
-    // k-loop: the (1+NT)*U loads of a group are issued before its first MFMA; steps past KS
-    // (wave-uniform) load nothing and multiply zeros.
-    for (int ks = kpart; ks < KS; ks += U * SK) {
-        VT a[U];
-        VT w[U][NT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k1 = ks + u * SK;
-            const VT* wk = wp + size_t(k1) * NTILES * 64;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w[u][t] = (k1 < KS && nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = (ks + u * SK < KS) ? load_a(ks + u * SK) : vec_zero<T>();
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (nt0 + t < NTILES) Mfma<T>::step(w[u][t], a[u], acc[t]);
-    }
-
-    if constexpr (SK > 1) {
-        __shared__ float s_red[(SK - 1) * NT * 16 * 64];
-        if (wave > 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s_red[((wave - 1) * NT * 16 + t * 16 + r) * 64 + lane] = acc[t][r];
-        }
-        lds_barrier();
-        if (wave > 0) return;
-#pragma unroll
-        for (int w = 0; w < SK - 1; ++w)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] += s_red[(w * NT * 16 + t * 16 + r) * 64 + lane];
-    }
-
-    if (!rvalid) return;
     using OT = T __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (nt0 + t >= NTILES) continue;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int n0 = (nt0 + t) * 32 + 8 * qq + 4 * g;
-            if (n0 >= N) continue;
-            const float4v bv = *reinterpret_cast<const float4v*>(bias + n0);
-            float y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                y[r] = acc[t][4 * qq + r] + bv[r];
-                if constexpr (ACT == ACT_SWISH) y[r] = swish_f<IsF32<T>::value>(y[r]);
-            }
-            if constexpr (RES) {
-                const OT rv = *reinterpret_cast<const OT*>(res + size_t(row) * N + n0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] += float(rv[r]);
-            }
-            OT o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = T(y[r]);
-            *reinterpret_cast<OT*>(out + size_t(row) * N + n0) = o;
-        }
-    }
-}
-
-// Register-blocked form of the split-K kernel for deep contractions with MANY rows: a workgroup owns
-// 64 rows x 64 out-channels (2 x 2 MFMA tiles per wave), its 4 waves still split the k-steps
-// interleaved and combine through LDS in wave order -- the partial sums and the order of
-// whenet_pw_kernel<T,1,8,4,..>, so the bits do not change -- but every operand fragment feeds two
-// MFMAs: half the L2 -> CU traffic per flop (the 1 x 1 form re-reads an activation strip once per
-// out-channel tile and a weight tile once per 32 rows: 8x the algorithmic bytes at 64 crops).
-template <typename T, bool GATE, bool RES, int ACT>
-__global__ __launch_bounds__(256, 2) void whenet_pw_split2_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
-                                                               const float* __restrict__ bias,
-                                                               const float* __restrict__ gate,
-                                                               const T* __restrict__ res, T* __restrict__ out, int M,
-                                                               int K, int N, int KS, int NTILES, int HW, int MT,
-                                                               int NCH) {
-    constexpr int V = Vec<T>::V;
-    using VT = typename Vec<T>::type;
-    constexpr int MB = 2, NT = 2, U = 4, SK = 4;
-    __shared__ float s_red[(SK - 1) * MB * NT * 16 * 64];
+    constexpr int MB = B2, NT = B2, SK = 4;
+    constexpr int U = (B2 == 2) ? 2 : 4;            // k-steps per load group; two groups are in flight
+    constexpr int NACC = MB * NT * 16, SL = NACC / 4;
+    __shared__ float s_red[4 * 3 * SL * 64];        // [owner][source (3 others)][SL][lane]
 
     const int id = blockIdx.x;
     const int q = id >> 3;
@@ -193,15 +71,14 @@ __global__ __launch_bounds__(256, 2) void whenet_pw_split2_kernel(const T* __res
     const int kpart = threadIdx.x >> 6;
     const int nt0 = nch * NT;
     const int g = lane >> 5;
-    int row[MB];
     bool rvalid[MB];
     const T* ap[MB];
-    const float* gp[MB];
+    const T* gp[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-        row[mb] = (mt * MB + mb) * 32 + (lane & 31);
-        rvalid[mb] = row[mb] < M;
-        const int rowc = rvalid[mb] ? row[mb] : (M - 1);
+        const int row = (mt * MB + mb) * 32 + (lane & 31);
+        rvalid[mb] = row < M;
+        const int rowc = rvalid[mb] ? row : (M - 1);
         ap[mb] = A + size_t(rowc) * K + g * V;
         gp[mb] = GATE ? gate + size_t(rowc / HW) * K + g * V : nullptr;
     }
@@ -215,97 +92,112 @@ __global__ __launch_bounds__(256, 2) void whenet_pw_split2_kernel(const T* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.0f;
 
-    auto load_a = [&](int mb, int ks) -> VT {
-        VT a = vec_zero<T>();
-        if (rvalid[mb] && ks * 2 * V + g * V < K) {
-            a = *reinterpret_cast<const VT*>(ap[mb] + ks * 2 * V);
-            if constexpr (GATE) {
-                float f[V];
-                vec_to_float<T>(a, f);
-#pragma unroll
-                for (int i = 0; i < V; i += 4) {
-                    const float4v gv = *reinterpret_cast<const float4v*>(gp[mb] + ks * 2 * V + i);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f[i + j] *= gv[j];
-                }
-                a = float_to_vec<T>(f);
-            }
-        }
-        return a;
+    struct Ops {
+        VT a[U][MB], g[U][MB], w[U][NT];
     };
-
-    for (int ks = kpart; ks < KS; ks += U * SK) {
-        VT a[U][MB];
-        VT w[U][NT];
+    auto issue = [&](int ks, Ops& o) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k1 = ks + u * SK;
+            const bool ok = k1 < KS;                                   // (wave-uniform)
             const VT* wk = wp + size_t(k1) * NTILES * 64;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w[u][t] = (k1 < KS && nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
-        }
+            for (int t = 0; t < NT; ++t) o.w[u][t] = (ok && nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a[u][mb] = (ks + u * SK < KS) ? load_a(mb, ks + u * SK) : vec_zero<T>();
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (nt0 + t < NTILES) Mfma<T>::step(w[u][t], a[u][mb], acc[mb][t]);
-    }
-
-    if (kpart > 0) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    s_red[(((kpart - 1) * MB + mb) * NT + t) * 1024 + r * 64 + lane] = acc[mb][t][r];
-    }
-    lds_barrier();
-    if (kpart > 0) return;
-#pragma unroll 1
-    for (int w = 0; w < SK - 1; ++w)                 // (not unrolled: 64 LDS values in registers at a time)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][t][r] += s_red[((w * MB + mb) * NT + t) * 1024 + r * 64 + lane];
-
-    using OT = T __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        if (!rvalid[mb]) continue;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (nt0 + t >= NTILES) continue;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int n0 = (nt0 + t) * 32 + 8 * qq + 4 * g;
-                if (n0 >= N) continue;
-                const float4v bv = *reinterpret_cast<const float4v*>(bias + n0);
-                float y[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    y[r] = acc[mb][t][4 * qq + r] + bv[r];
-                    if constexpr (ACT == ACT_SWISH) y[r] = swish_f<IsF32<T>::value>(y[r]);
-                }
-                if constexpr (RES) {
-                    const OT rv = *reinterpret_cast<const OT*>(res + size_t(row[mb]) * N + n0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] += float(rv[r]);
-                }
-                OT o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = T(y[r]);
-                *reinterpret_cast<OT*>(out + size_t(row[mb]) * N + n0) = o;
+            for (int mb = 0; mb < MB; ++mb) {
+                const bool la = ok && rvalid[mb] && k1 * 2 * V + g * V < K;
+                o.a[u][mb] = la ? *reinterpret_cast<const VT*>(ap[mb] + k1 * 2 * V) : vec_zero<T>();
+                if constexpr (GATE)
+                    o.g[u][mb] = la ? *reinterpret_cast<const VT*>(gp[mb] + k1 * 2 * V) : vec_zero<T>();
             }
         }
+    };
+    auto compute = [&](const Ops& o) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                VT a = o.a[u][mb];
+                if constexpr (GATE) a = a * o.g[u][mb];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nt0 + t < NTILES) Mfma<T>::step(o.w[u][t], a, acc[mb][t]);
+            }
+    };
+
+    Ops o0, o1;
+    issue(kpart, o0);
+    for (int ks = kpart; ks < KS; ks += 2 * U * SK) {
+        issue(ks + U * SK, o1);
+        compute(o0);
+        issue(ks + 2 * U * SK, o0);
+        if (ks + U * SK < KS) compute(o1);
+    }
+
+    // ---- combine: wave p owns accumulators [p*SL, (p+1)*SL) of the flattened (mb, t, r) index -----
+    const int f0 = kpart * SL;                       // first flattened accumulator of this wave's slice
+    const int own_tile = f0 >> 4, own_mb = own_tile / NT, own_t = own_tile % NT;
+    const int own_row = (mt * MB + own_mb) * 32 + (lane & 31);
+    const bool own_valid = own_row < M && nt0 + own_t < NTILES;
+    OT rv[SL / 4];
+    float4v bv[SL / 4];
+#pragma unroll
+    for (int i4 = 0; i4 < SL / 4; ++i4) {            // skip rows and bias of the slice: in flight across the exchange
+        const int qq = ((f0 & 15) >> 2) + i4;
+        const int n0 = (nt0 + own_t) * 32 + 8 * qq + 4 * g;
+        const bool ok = own_valid && n0 < N;
+        bv[i4] = ok ? *reinterpret_cast<const float4v*>(bias + n0) : float4v{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES) rv[i4] = ok ? *reinterpret_cast<const OT*>(res + size_t(own_row) * N + n0) : OT{};
+    }
+    float own[SL];
+#pragma unroll
+    for (int dst = 0; dst < 4; ++dst) {
+        if (dst == kpart) {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int f = dst * SL + i;
+                own[i] = acc[(f >> 4) / NT][(f >> 4) % NT][f & 15];
+            }
+        } else {
+            const int src = (kpart < dst) ? kpart : kpart - 1;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int f = dst * SL + i;
+                s_red[((dst * 3 + src) * SL + i) * 64 + lane] = acc[(f >> 4) / NT][(f >> 4) % NT][f & 15];
+            }
+        }
+    }
+    lds_barrier();
+    float sum[SL];
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {
+        if (src == kpart) {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) sum[i] = (src == 0) ? own[i] : sum[i] + own[i];
+        } else {
+            const int si = (src < kpart) ? src : src - 1;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const float v = s_red[((kpart * 3 + si) * SL + i) * 64 + lane];
+                sum[i] = (src == 0) ? v : sum[i] + v;
+            }
+        }
+    }
+    if (!own_valid) return;
+#pragma unroll
+    for (int i4 = 0; i4 < SL / 4; ++i4) {
+        const int qq = ((f0 & 15) >> 2) + i4;
+        const int n0 = (nt0 + own_t) * 32 + 8 * qq + 4 * g;
+        if (n0 >= N) continue;
+        OT o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float y = sum[4 * i4 + r] + bv[i4][r];
+            if constexpr (ACT == ACT_SWISH) y = swish_f<IsF32<T>::value>(y);
+            if constexpr (RES) y += float(rv[i4][r]);
+            o[r] = T(y);
+        }
+        *reinterpret_cast<OT*>(out + size_t(own_row) * N + n0) = o;
     }
 }
 
@@ -325,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void whenet_pw_split2_kernel(const T* __res
 template <typename T, int NT, bool GATE, bool RES, int ACT>
 __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
                                                              const float* __restrict__ bias,
-                                                             const float* __restrict__ gate,
+                                                             const T* __restrict__ gate,
                                                              const T* __restrict__ res, T* __restrict__ out, int M,
                                                              int K, int N, int KS, int NTILES, int HW, int MT,
                                                              int NCH) {
@@ -360,7 +252,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     const int rowc = rvalid ? row : (M - 1);
 
     const T* ap = A + size_t(rowc) * K + g * V;
-    const float* gp = nullptr;
+    const T* gp = nullptr;
     if constexpr (GATE) gp = gate + size_t(rowc / HW) * K + g * V;
     const VT* wsrc = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64;
 
@@ -374,17 +266,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
         VT a = vec_zero<T>();
         if (rvalid && ks < KS && ks * 2 * V + g * V < K) {
             a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
-            if constexpr (GATE) {
-                float f[V];
-                vec_to_float<T>(a, f);
-#pragma unroll
-                for (int i = 0; i < V; i += 4) {
-                    const float4v gv = *reinterpret_cast<const float4v*>(gp + ks * 2 * V + i);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f[i + j] *= gv[j];
-                }
-                a = float_to_vec<T>(f);
-            }
+            if constexpr (GATE) a = a * *reinterpret_cast<const VT*>(gp + ks * 2 * V);      // T x T, one rounding
         }
         return a;
     };
@@ -502,7 +384,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
 template <typename T, bool GATE, bool RES, int ACT>
 __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restrict__ A, const float* __restrict__ Wd,
                                                               const float* __restrict__ bias,
-                                                              const float* __restrict__ gate,
+                                                              const T* __restrict__ gate,
                                                               const T* __restrict__ res, T* __restrict__ out, int M,
                                                               int K, int N, int HW) {
     const int n4 = N / 4;
@@ -511,11 +393,11 @@ __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restric
     const int m = int(idx / n4);
     const int n0 = int(idx - size_t(m) * n4) * 4;
     const T* ap = A + size_t(m) * K;
-    const float* gp = GATE ? gate + size_t(m / HW) * K : nullptr;
+    const T* gp = GATE ? gate + size_t(m / HW) * K : nullptr;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K; ++k) {
         float a = float(ap[k]);
-        if constexpr (GATE) a = float(T(a * gp[k]));
+        if constexpr (GATE) a = float(T(a * float(gp[k])));      // T x T product, rounded once
         const float4v w = *reinterpret_cast<const float4v*>(Wd + size_t(k) * N + n0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaf(a, w[r], acc[r]);
@@ -564,20 +446,20 @@ PwChoice choose_pw(const PwArgs& a, int num_cus) {
     return PwChoice{2, NT, ceil_div(a.NTILES, NT)};
 }
 
-template <typename T, int NT, int U, int SK, bool GATE, bool RES, int ACT>
-void launch_mfma(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
-    const int blocks = 8 * ceil_div(MT, 8) * NCH;
-    hipLaunchKernelGGL((whenet_pw_kernel<T, NT, U, SK, GATE, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
-                       static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, a.gate,
-                       static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES, a.HW, MT,
-                       NCH);
+template <typename T, int B2, bool GATE, bool RES, int ACT>
+void launch_splitk(const PwArgs& a, hipStream_t stream) {
+    const int MT = ceil_div(a.M, 32 * B2), NCH = ceil_div(a.NTILES, B2);
+    hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GATE, RES, ACT>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
+                       stream, static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias,
+                       static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
+                       a.N, a.KS, a.NTILES, a.HW, MT, NCH);
 }
 
 template <typename T, int NT, bool GATE, bool RES, int ACT>
 void launch_tile(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
     const int blocks = 8 * ceil_div(MT, 8) * NCH;
     hipLaunchKernelGGL((whenet_pw_tile_kernel<T, NT, GATE, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
-                       static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, a.gate,
+                       static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, static_cast<const T*>(a.gate),
                        static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES, a.HW, MT,
                        NCH);
 }
@@ -587,21 +469,14 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
     if (impl == 1) {
         const size_t work = size_t(a.M) * (a.N / 4);
         hipLaunchKernelGGL((whenet_pw_check_kernel<T, GATE, RES, ACT>), dim3(unsigned((work + 255) / 256)), dim3(256),
-                           0, stream, static_cast<const T*>(a.a), a.wdense, a.bias, a.gate,
+                           0, stream, static_cast<const T*>(a.a), a.wdense, a.bias, static_cast<const T*>(a.gate),
                            static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.HW);
         return;
     }
     const PwChoice ch = choose_pw(a, num_cus);
     if (ch.kind == 1) {
-        if (use_split2(a.M, a.NTILES)) {
-            const int MT2 = ceil_div(a.M, 64), NCH2 = ceil_div(a.NTILES, 2);
-            hipLaunchKernelGGL((whenet_pw_split2_kernel<T, GATE, RES, ACT>), dim3(8 * ceil_div(MT2, 8) * NCH2), dim3(256),
-                               0, stream, static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, a.gate,
-                               static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES,
-                               a.HW, MT2, NCH2);
-            return;
-        }
-        launch_mfma<T, 1, 8, 4, GATE, RES, ACT>(a, ceil_div(a.M, 32), a.NTILES, stream);
+        if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, GATE, RES, ACT>(a, stream);
+        else launch_splitk<T, 1, GATE, RES, ACT>(a, stream);
         return;
     }
     const int MT = ceil_div(a.M, 128);
@@ -644,9 +519,9 @@ std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
         std::snprintf(buf, sizeof(buf), "whenet_pw_check_kernel<%s, %s, %s, %d>", t, gate, res, a.act);
     } else {
         const PwChoice ch = choose_pw(a, num_cus);
-        if (ch.kind == 1 && use_split2(a.M, a.NTILES))
-            std::snprintf(buf, sizeof(buf), "whenet_pw_split2_kernel<%s, %s, %s, %d>", t, gate, res, a.act);
-        else if (ch.kind == 1) std::snprintf(buf, sizeof(buf), "whenet_pw_kernel<%s, 1, 8, 4, %s, %s, %d>", t, gate, res, a.act);
+        if (ch.kind == 1)
+            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk_kernel<%s, %d, %s, %s, %d>", t,
+                          use_split2(a.M, a.NTILES) ? 2 : 1, gate, res, a.act);
         else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d>", t, ch.NT, gate, res, a.act);
     }
     return buf;

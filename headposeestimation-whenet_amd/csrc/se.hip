@@ -25,11 +25,17 @@ namespace whenet {
 
 namespace {
 
+// The gate is stored in the type of the activations it multiplies (pw.hip applies it as a T x T product).
+__device__ __forceinline__ void store_gate(void* gate, int f16, size_t i, float v) {
+    if (f16) static_cast<half_t*>(gate)[i] = half_t(v);
+    else static_cast<float*>(gate)[i] = v;
+}
+
 template <int RP>
 __global__ __launch_bounds__(1024) void whenet_se_kernel(const float* __restrict__ partial, int ntiles, float inv_hw,
                                                         const float* __restrict__ w1t, const float* __restrict__ b1,
                                                         const float* __restrict__ w2c, const float* __restrict__ b2,
-                                                        float* __restrict__ gate, int C, int R) {
+                                                        void* __restrict__ gate, int C, int R, int gate_f16) {
     constexpr int NW = 16, NTHR = NW * 64;
     constexpr int JPW = (RP + NW - 1) / NW;          // fc1 outputs per wave (<= 3)
     constexpr int CPL = 1152 / 64;                    // channel slots per lane (18)
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(1024) void whenet_se_kernel(const float* __restrict
                 t2 = fmaf(s_r[j + 2], wv2[ci][j + 2], t2);
                 t3 = fmaf(s_r[j + 3], wv2[ci][j + 3], t3);
             }
-            gate[size_t(b) * C + c] = sigmoid_f<true>((t0 + t1) + (t2 + t3));
+            store_gate(gate, gate_f16, size_t(b) * C + c, sigmoid_f<true>((t0 + t1) + (t2 + t3)));
         }
     }
     STAMP(5);
@@ -167,8 +173,8 @@ template <int RP>
 __global__ __launch_bounds__(256) void whenet_se_excite_kernel(const float* __restrict__ rpart, int np, float inv_hw,
                                                                const float* __restrict__ b1,
                                                                const float* __restrict__ w2c,
-                                                               const float* __restrict__ b2, float* __restrict__ gate,
-                                                               int C, int R, int SPLIT) {
+                                                               const float* __restrict__ b2, void* __restrict__ gate,
+                                                               int C, int R, int SPLIT, int gate_f16) {
     constexpr int NTHR = 256;
     constexpr int NCI = 2;                            // channels per lane (slice <= 512)
     __shared__ float s_r[RP];
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void whenet_se_excite_kernel(const float* __re
                 t2 = fmaf(s_r[j + 2], wv[ci][j + 2], t2);
                 t3 = fmaf(s_r[j + 3], wv[ci][j + 3], t3);
             }
-            gate[size_t(b) * C + c] = sigmoid_f<true>((t0 + t1) + (t2 + t3));
+            store_gate(gate, gate_f16, size_t(b) * C + c, sigmoid_f<true>((t0 + t1) + (t2 + t3)));
         }
     }
     STAMP(3);
@@ -231,13 +237,13 @@ template <int RP>
 void launch_ex(const SeExciteArgs& a, hipStream_t stream) {
     const int split = se_excite_split(a.C);
     hipLaunchKernelGGL(whenet_se_excite_kernel<RP>, dim3(a.n * split), dim3(256), 0, stream, a.rpart, a.np, a.inv_hw,
-                       a.b1, a.w2c, a.b2, a.gate, a.C, a.R, split);
+                       a.b1, a.w2c, a.b2, a.gate, a.C, a.R, split, a.gate_f16);
 }
 
 template <int RP>
 void launch_rp(const SeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(whenet_se_kernel<RP>, dim3(a.n), dim3(1024), 0, stream, a.partial, a.ntiles, a.inv_hw, a.w1t,
-                       a.b1, a.w2c, a.b2, a.gate, a.C, a.R);
+                       a.b1, a.w2c, a.b2, a.gate, a.C, a.R, a.gate_f16);
 }
 
 }  // namespace
