@@ -37,6 +37,12 @@ namespace {
 constexpr int P = 7;
 constexpr int VC = 4;
 
+// q / d for 0 <= q < 2^20 and 0 < d < 512, exact, with rinv = 1 / float(d) (1 ulp): (q + 0.5) / d is at least
+// 0.5 / d away from an integer, far more than the rounding of the three float operations.  An integer
+// division by a run-time divisor is ~25 instructions on this ISA, four of them quarter-rate 32-bit multiplies;
+// this kernel used to spend a third of its VALU cycles in them.
+__device__ __forceinline__ int fdiv(int q, float rinv) { return int((float(q) + 0.5f) * rinv); }
+
 template <typename T, int K, int S, int NTHR>
 __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restrict__ x, const T* __restrict__ wep,
                                                             const float* __restrict__ be,
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     const int RW = ix_hi - ix_lo, npx = (iy_hi - iy_lo) * RW;
     const int nstrip = (npx + 31) >> 5, ntile = (ccur + 31) >> 5;
     const int ntask = nstrip * ntile;
+    const float r_nstrip = __builtin_amdgcn_rcpf(float(nstrip)), r_rw = __builtin_amdgcn_rcpf(float(RW));
 
     struct Task {
         bool valid;
@@ -89,22 +96,25 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     };
     auto make_task = [&](int t) -> Task {
         Task k;
-        k.tl = t / nstrip;
+        k.tl = fdiv(t, r_nstrip);
         const int strip = t - k.tl * nstrip;
         const int q = strip * 32 + lm;
         k.valid = t < ntask && q < npx;
-        const int ry = k.valid ? q / RW : 0, rx = k.valid ? q - ry * RW : 0;
+        const int ry = k.valid ? fdiv(q, r_rw) : 0, rx = k.valid ? q - ry * RW : 0;
         const int iy = iy_lo + ry, ix = ix_lo + rx;
         k.xrow = x + ((size_t(b) * H + iy) * H + ix) * Cin + g * V;
         k.eoff = ((iy - iy0) * EW + (ix - ix0)) * EP;
         k.wf = reinterpret_cast<const VT*>(wep) + size_t((c0 >> 5) + k.tl) * 64 + lane;
         return k;
     };
-    auto load_ops = [&](const Task& k, int ks, VT (&w)[4], VT (&a)[4]) {
+    // PF k-steps of operands travel together (8 was measured: it spills at the 128-register budget of 4
+    // workgroups per CU and loses 25 %)
+    constexpr int PF = 4;
+    auto load_ops = [&](const Task& k, int ks, VT (&w)[PF], VT (&a)[PF]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = (ks + u < KSe) ? k.wf[size_t(ks + u) * NTe * 64] : vec_zero<T>();
+        for (int u = 0; u < PF; ++u) w[u] = (ks + u < KSe) ? k.wf[size_t(ks + u) * NTe * 64] : vec_zero<T>();
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < PF; ++u)
             a[u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
                        ? *reinterpret_cast<const VT*>(k.xrow + size_t(ks + u) * 2 * V)
                        : vec_zero<T>();
@@ -121,16 +131,19 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     // depthwise taps, then the first task's operands; the taps are parked in LDS and E is zeroed (the
     // halo outside the image is TF 'SAME' padding of the EXPANDED tensor) while the operands are
     // still in flight -- the barrier below orders LDS traffic only.
-    constexpr int WR = (K * K * 160 + NTHR - 1) / NTHR;
-    float wreg[WR];
+    // (lane -> (tap, channel) without a division: 32 channels x NTHR/32 taps per pass)
+    constexpr int TPP = NTHR / 32;                              // taps per pass
+    constexpr int WT = (K * K + TPP - 1) / TPP, WC = (K == 5) ? 4 : 5;     // passes over taps x 32-channel groups
+    float wreg[WT][WC];
 #pragma unroll
-    for (int j = 0; j < WR; ++j) {
-        const int i = tid + j * NTHR;
-        const int tap = i / ccur, c = i - tap * ccur;
-        wreg[j] = (i < K * K * ccur) ? wd[size_t(tap) * Cexp + c0 + c] : 0.f;
-    }
+    for (int jt = 0; jt < WT; ++jt)
+#pragma unroll
+        for (int jc = 0; jc < WC; ++jc) {
+            const int tap = (tid >> 5) + jt * TPP, c = (tid & 31) + 32 * jc;
+            wreg[jt][jc] = (tap < K * K && c < ccur) ? wd[size_t(tap) * Cexp + c0 + c] : 0.f;
+        }
     Task cur = make_task(wave);
-    VT w[4], a[4];
+    VT w[PF], a[PF];
     float4v bv[4];
     if (wave < ntask) {
         load_bias(cur, bv);
@@ -138,11 +151,12 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     }
     for (int i = tid; i < EH * EW * EP / 16; i += NTHR) reinterpret_cast<VT*>(E)[i] = vec_zero<T>();
 #pragma unroll
-    for (int j = 0; j < WR; ++j) {
-        const int i = tid + j * NTHR;
-        const int tap = i / ccur, c = i - tap * ccur;
-        if (i < K * K * ccur) s_w[tap * CC + c] = wreg[j];
-    }
+    for (int jt = 0; jt < WT; ++jt)
+#pragma unroll
+        for (int jc = 0; jc < WC; ++jc) {
+            const int tap = (tid >> 5) + jt * TPP, c = (tid & 31) + 32 * jc;
+            if (tap < K * K && c < ccur) s_w[tap * CC + c] = wreg[jt][jc];
+        }
     lds_barrier();
     STAMP(1);
 
@@ -151,11 +165,11 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Mfma<T>::step(w[u], a[u], acc);
-        for (int ks = 4; ks < KSe; ks += 4) {
+        for (int u = 0; u < PF; ++u) Mfma<T>::step(w[u], a[u], acc);
+        for (int ks = PF; ks < KSe; ks += PF) {
             load_ops(cur, ks, w, a);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Mfma<T>::step(w[u], a[u], acc);
+            for (int u = 0; u < PF; ++u) Mfma<T>::step(w[u], a[u], acc);
         }
         const Task nxt = make_task(t + NWAVE);
         if (t + NWAVE < ntask) load_ops(nxt, 0, w, a);
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int nl = cur.tl * 32 + 8 * qq + 4 * g;
-                if (nl < ccur) {
+                if (cur.tl * 32 + 8 * qq < ccur) {          // (wave-uniform: chunk widths are multiples of 8)
                     OT o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = T(swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[qq][r]));
@@ -194,9 +208,9 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     // ---- depthwise taps out of E: lane = (4-channel group cg, strip sidx) ---------------------
     const int CG = ccur / VC;
     const int NPC = (NTHR / CG < TH * NSX) ? NTHR / CG : TH * NSX;    // tap slots (strips) in use
-    const int cg = tid % CG;
-    const int sidx = tid / CG;
-    const int ty = sidx / NSX, sx = sidx - ty * NSX;
+    const int sidx = fdiv(tid, __builtin_amdgcn_rcpf(float(CG)));
+    const int cg = tid - sidx * CG;
+    const int ty = fdiv(sidx, __builtin_amdgcn_rcpf(float(NSX))), sx = sidx - ty * NSX;
     const int oy = oy0 + ty;
     const bool lane_ok = sidx < NPC;
     const bool active = lane_ok && (sidx < TH * NSX) && (oy < Ho);
@@ -205,6 +219,8 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int v = 0; v < VC; ++v) acc[p][v] = 0.0f;
+    const unsigned char* row0 = E + ((ty * S) * EW + sx * P * S) * EP + cg * VC * SZ;
+    const int row_pitch = EW * EP;
     if (active) {
 #pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
@@ -215,10 +231,10 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
 #pragma unroll
                 for (int v = 0; v < VC; ++v) wr[kx][v] = wv[v];
             }
-            const unsigned char* row = E + size_t((ty * S + ky) * EW + sx * P * S) * EP + cg * VC * SZ;
+            const unsigned char* row = row0 + ky * row_pitch;
 #pragma unroll
             for (int ix = 0; ix < NIX; ++ix) {
-                const VCT xv = *reinterpret_cast<const VCT*>(row + size_t(ix) * EP);
+                const VCT xv = *reinterpret_cast<const VCT*>(row + ix * EP);
                 float xf[VC];
 #pragma unroll
                 for (int v = 0; v < VC; ++v) xf[v] = float(xv[v]);
@@ -405,7 +421,7 @@ std::vector<FrontPlan> plan_front_candidates(int dtype, int k, int s, int H, int
                                              std::vector<double>* scores) {
     constexpr int NTHR = 256;           // tap lanes the tile is planned for (the kernel may run more lanes)
     const int SZ = (dtype == WHENET_F16) ? 2 : 4;
-    WHENET_REQUIRE(Cexp % VC == 0 && Ho % P == 0, WHENET_EINVAL, "front: unsupported geometry");
+    WHENET_REQUIRE(Cexp % 8 == 0 && Ho % P == 0, WHENET_EINVAL, "front: unsupported geometry");
     const int spr = Ho / P;
     std::vector<FrontPlan> out;
     for (int CC = 32; CC <= 160; CC += 32) {
