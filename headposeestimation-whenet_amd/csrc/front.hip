@@ -88,6 +88,8 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     const int ntask = nstrip * ntile;
     const float r_nstrip = __builtin_amdgcn_rcpf(float(nstrip)), r_rw = __builtin_amdgcn_rcpf(float(RW));
 
+    const T* xb = x + size_t(b) * H * H * Cin;
+    const VT* wf0 = reinterpret_cast<const VT*>(wep) + size_t(c0 >> 5) * 64;
     struct Task {
         bool valid;
         int tl, eoff;
@@ -102,9 +104,9 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         k.valid = t < ntask && q < npx;
         const int ry = k.valid ? fdiv(q, r_rw) : 0, rx = k.valid ? q - ry * RW : 0;
         const int iy = iy_lo + ry, ix = ix_lo + rx;
-        k.xrow = x + ((size_t(b) * H + iy) * H + ix) * Cin + g * V;
+        k.xrow = xb + ((iy * H + ix) * Cin + g * V);            // (32-bit offsets inside the crop)
         k.eoff = ((iy - iy0) * EW + (ix - ix0)) * EP;
-        k.wf = reinterpret_cast<const VT*>(wep) + size_t((c0 >> 5) + k.tl) * 64 + lane;
+        k.wf = wf0 + (k.tl * 64 + lane);
         return k;
     };
     // PF k-steps of operands travel together (8 was measured: it spills at the 128-register budget of 4
@@ -112,11 +114,11 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     constexpr int PF = 4;
     auto load_ops = [&](const Task& k, int ks, VT (&w)[PF], VT (&a)[PF]) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) w[u] = (ks + u < KSe) ? k.wf[size_t(ks + u) * NTe * 64] : vec_zero<T>();
+        for (int u = 0; u < PF; ++u) w[u] = (ks + u < KSe) ? k.wf[(ks + u) * NTe * 64] : vec_zero<T>();
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             a[u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
-                       ? *reinterpret_cast<const VT*>(k.xrow + size_t(ks + u) * 2 * V)
+                       ? *reinterpret_cast<const VT*>(k.xrow + (ks + u) * 2 * V)
                        : vec_zero<T>();
     };
     auto load_bias = [&](const Task& k, float4v (&bv)[4]) {
