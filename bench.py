@@ -30,7 +30,12 @@ Extra objects on the line:
   latency_b1    configs[1]: batch=1 fp32 single-crop latency (median / p99), N=1 only
   frame_pipeline  configs[4]: one video frame + k head boxes per submission (PCIe included), N=1 only
   pcie_inclusive  the host-pointer forms on the same batch, H2D + D2H included (never `value`)
-  serial_schedule the timed region with one forward at a time
+  serial_schedule the timed region with one forward at a time (also as top-level `value_serial` /
+                `ms_per_step_serial`)
+  config.per_rank_crops_s / world_size / backend   what each rank did on its own clock, the RCCL world
+
+--strong: a fixed global batch (--global-batch, default 512) split over the ranks ("scaling": "strong");
+the default is weak scaling (the same --batch on every rank).
 """
 from __future__ import annotations
 
@@ -51,7 +56,6 @@ for p in (PKG, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-EMPTY_KERNEL_US = 4.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 PATH_BOUND_CROPS_S = {          # BASELINE.md §2, per GPU, f16, 6.29 TB/s
     "layer_granular": 227280.0, "mbconv_2kernel_fusion": 453209.0}
@@ -60,8 +64,9 @@ PATH_BOUND_CROPS_S = {          # BASELINE.md §2, per GPU, f16, 6.29 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400,
+                    help="timed steps (default 400: >= 200 ms timed at batch 64)")
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--profile-iters", type=int, default=20)
@@ -76,7 +81,10 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="concurrent sub-batch chains per forward (0 = engine default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="engine option passed to whenet_set_option (e.g. trunk=0)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: a fixed GLOBAL batch (--global-batch, default 512) split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=512, help="global batch of --strong")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--dump-layers", default="", help="write the per-launch profile (JSON) to this path")
     return ap.parse_args()
 
@@ -95,36 +103,55 @@ def cpu_baseline(seconds: float):
     """Reference-faithful CPU path (oracle/whenet_torch.py: float64 normalise, batch_size=8
     chunks as whenet.py:27, numpy decode) on the host cores; bounded sample.  torch's default of
     one thread per logical CPU is far from the best setting for batch-8 convolutions on a
-    many-core host, so a few thread counts are tried and the best is reported."""
+    many-core host, so a few thread counts are tried (short runs), then the best is timed for
+    >= 5 s: that stable sample is `value`.  `best_cpu` is the same model WITHOUT the reference's
+    batch_size=8 chunking (one 64-crop forward per call, best thread count of its own sweep): what
+    the host could do if whenet.py:27 did not chunk -- the strongest CPU row, not the reference's."""
     from whenet_hip import weights as W, synth
     from oracle.whenet_torch import TorchWHENet
     m = TorchWHENet(W.synthetic(1234))
-    crops = synth.noise_crops(8, seed=0)
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
     cands = sorted({t for t in (8, 16, 32, 64, default_threads) if t <= max(ncpu, 1)})
-    per = max(seconds / (len(cands) + 1), 1.5)
-    tried = {}
-    for t in cands:
-        torch.set_num_threads(t)
-        m.get_angle(crops.copy())                  # warm-up
+    stable = max(5.0, seconds * 0.25)
+    probe = max((seconds - 2 * stable) / (2 * len(cands)), 0.8)
+
+    def rate(crops, chunk, secs):
         done, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < per:
-            m.get_angle(crops.copy())
+        while True:
+            m.get_angle(crops.copy(), batch_size=chunk)
             done += crops.shape[0]
-        tried[t] = done / (time.perf_counter() - t0)
-    best = max(tried, key=tried.get)
-    torch.set_num_threads(best)
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < per:
-        m.get_angle(crops.copy())
-        done += crops.shape[0]
-    el = time.perf_counter() - t0
-    torch.set_num_threads(default_threads)
-    return {"value": done / el, "unit": "crops/s", "cores": int(best), "kind": "port",
+            el = time.perf_counter() - t0
+            if el >= secs:
+                return done / el, done, el
+
+    def sweep(crops, chunk):
+        tried = {}
+        for t in cands:
+            torch.set_num_threads(t)
+            m.get_angle(crops.copy(), batch_size=chunk)                  # warm-up
+            tried[t] = rate(crops, chunk, probe)[0]
+        best = max(tried, key=tried.get)
+        torch.set_num_threads(best)
+        v, done, el = rate(crops, chunk, stable)
+        return best, tried, v, done, el
+
+    try:
+        c8 = synth.noise_crops(8, seed=0)
+        best, tried, v, done, el = sweep(c8, 8)
+        c64 = synth.noise_crops(64, seed=0)
+        bbest, btried, bv, bdone, bel = sweep(c64, 64)
+    finally:
+        torch.set_num_threads(default_threads)
+    return {"value": v, "unit": "crops/s", "cores": int(best), "kind": "port",
             "sample": f"{done} crops as batches of 8 (whenet.py:27 batch_size=8) in {el:.1f} s at {best} threads; "
                       f"torch-CPU f32 restatement of whenet.py:22-34 incl. float64 normalise + numpy decode; "
-                      f"crops/s by thread count: " + ", ".join(f"{k}: {v:.1f}" for k, v in sorted(tried.items())),
+                      f"crops/s by thread count ({probe:.1f} s probes): " +
+                      ", ".join(f"{k}: {x:.1f}" for k, x in sorted(tried.items())),
+            "best_cpu": {"value": bv, "unit": "crops/s", "cores": int(bbest),
+                         "sample": f"{bdone} crops as un-chunked 64-crop forwards in {bel:.1f} s at {bbest} threads "
+                                   f"(NOT the reference's schedule: whenet.py:27 chunks by 8); by thread count: " +
+                                   ", ".join(f"{k}: {x:.1f}" for k, x in sorted(btried.items()))},
             "host_cpus": ncpu}
 
 
@@ -237,6 +264,11 @@ def main():
         h.set_option(k, int(v))
 
     B = args.batch
+    if args.strong:
+        # fixed global batch split over the ranks (whenet_hip/shard.py's partition): per-GPU work shrinks with N
+        from whenet_hip.shard import shard_bounds
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        B = hi - lo
     M = max(1, args.inflight)
     crops = synth.noise_crops(B, seed=rank)        # default_rng(seed) uint8
     d_crops = torch.from_numpy(crops).to(dev)
@@ -268,40 +300,50 @@ def main():
         fence()
         return time.perf_counter() - t0, enq
 
+    total_per_step = args.global_batch if args.strong else world * B      # crops all ranks process per step
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     serial = None
     if M > 1:
         if not args.no_serial:
             # the strictly serial schedule first (one forward at a time, 3 sub-batch lanes), for reference
             el1, _ = timed(1)
-            serial = {"value": world * B * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3, "in_flight": 1}
+            el1 = max_over_ranks(el1)
+            serial = {"value": total_per_step * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3, "in_flight": 1}
         h.set_option("inflight", M)
         if args.lanes > 0:
             h.set_option("lanes", args.lanes)
-    el, enq = timed(M)
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    el_rank, enq = timed(M)
+    el = max_over_ranks(el_rank)
+    value = total_per_step * args.steps / el
+    # what every rank did on its own clock (the driver computes scaling efficiency itself from `value`)
+    per_rank = [B * args.steps / el_rank]
     if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-    value = world * B * args.steps / el
+        g = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([per_rank[0]], dtype=torch.float64, device=dev))
+        per_rank = [float(x.item()) for x in g]
 
     # ---- per-kernel roofline (HIP events around every launch, same stream, eager) ----------
     stats = h.profile(d_crops.data_ptr(), B, args.profile_iters)
     if args.dump_layers and rank == 0:
         with open(args.dump_layers, "w") as f:
             json.dump({"batch": B, "dtype": args.dtype, "launches": stats}, f, indent=1)
-    # the last entry of a chain is an empty kernel timed the same way: event-to-event time of a
-    # launch = kernel duration + the boundary in front of it; the boundary estimate is subtracted
-    # (never more than 70 % of a launch) so that per-launch figures are kernel durations,
-    # comparable with rocprofv3's hardware timestamps
+    # A launch's figure is the event-to-event time on the chain's stream.  Back-to-back launches pipeline, so for
+    # a real kernel that IS its duration as rocprofv3's hardware timestamps report it (profiles/r02: the
+    # kernel-trace averages agree within a few %); only for an EMPTY kernel is the ~2-9 us event/dispatch gap
+    # exposed.  The chain's last entry is such an empty kernel: reported as `boundary_us`, never subtracted
+    # (round 1 subtracted it, which made the per-launch figures disagree with rocprofv3).
     boundary_us = 0.0
     if stats and stats[-1]["kind"] == "calib":
-        # the empty kernel itself lasts ~4 us in rocprofv3's trace under the same concurrency
-        # (profiles/r01/rocprofv3_kernel_stats_bench_default.csv: whenet_empty_kernel)
-        boundary_us = max(stats[-1]["avg_us"] - EMPTY_KERNEL_US, 0.0)
+        boundary_us = stats[-1]["avg_us"]
         stats = stats[:-1]
     for s in stats:
         s["raw_us"] = s["avg_us"]
-        s["avg_us"] = max(s["avg_us"] - boundary_us, 0.3 * s["avg_us"])
     by_kernel = {}
     for s in stats:
         k = by_kernel.setdefault(s["kernel"], {"us": 0.0, "bytes": 0.0, "flops": 0.0, "launches": 0, "kind": s["kind"]})
@@ -313,17 +355,23 @@ def main():
     achieved = dom["bytes"] / (dom["us"] * 1e-6) / 1e9
     # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in separate
     # rocprofv3 --pmc passes of this same command and committed under profiles/): per launch, bytes
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_{args.dtype}_b{B}.json")) as f:
-            tk = json.load(f)["kernels"]
+    traffic, traffic_source = None, None
+    for rnd in ("r02", "r01"):
+        rel = os.path.join("profiles", rnd, f"pmc_traffic_{args.dtype}_b{B}.json")
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                tk = json.load(f)["kernels"]
+        except (OSError, KeyError, ValueError):
+            continue
         for name, v in tk.items():
             if name.replace(" ", "") == dom_name.replace(" ", ""):
                 traffic = v["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+                traffic_source = (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in separate passes "
+                                  f"(tools/pmc_round.sh), committed file -- NOT re-measured by this run")
+        if traffic is not None:
+            break
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": dom_name, "launches_per_step": dom["launches"],
                 "avg_launch_us": dom["us"] / dom["launches"],
                 "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
@@ -331,8 +379,7 @@ def main():
                 "method": "one hipEvent between consecutive launches on the chain's stream; one forward of the batch "
                           "alone on the GPU (eager pass right after the timed region), as rocprofv3's kernel trace "
                           "sees it; the timed region overlaps `forwards_in_flight` such chains",
-                "boundary_us": boundary_us,
-                "avg_launch_us_raw": sum(s["raw_us"] for s in stats if s["kernel"] == dom_name) / dom["launches"],
+                "empty_kernel_event_to_event_us": boundary_us,
                 "chain_us_per_step": sum(s["raw_us"] for s in stats),
                 "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
                                   "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
@@ -343,12 +390,19 @@ def main():
         "metric": "head crops/sec (224x224)", "value": value, "unit": "crops/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
         "host_enqueue_ms_per_step": enq / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "value_serial": serial["value"] if serial else (value if M == 1 else None),
+        "ms_per_step_serial": serial["ms_per_step"] if serial else (el / args.steps * 1e3 if M == 1 else None),
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": f"batch={B}/GPU 224x224 uint8 crops resident in HBM -> angles+argmax+logits "
+        "config": {"workload": (f"global batch {total_per_step} split over {world} GPU(s) (strong scaling), " if args.strong
+                                else f"batch={B}/GPU ") +
+                               f"224x224 uint8 crops resident in HBM -> angles+argmax+logits "
                                f"(BASELINE.json configs[{2 if world == 1 else 3}])",
-                   "batch_per_gpu": B, "global_batch": B * world, "weights": "synthetic random-init seed 1234",
+                   "batch_per_gpu": B, "global_batch": total_per_step, "weights": "synthetic random-init seed 1234",
                    "parallelism": f"batch-shard x{world}, no data-path collective",
+                   "world_size": world, "backend": ("nccl (RCCL)" if distributed else "none (single process)"),
+                   "per_rank_crops_s": [round(x, 1) for x in per_rank],
                    "graph": not args.no_graph,
                    "forwards_in_flight": M,
                    "schedule": (f"{M} independent forwards of the batch in flight per GPU (engine option inflight={M}: "
@@ -369,7 +423,7 @@ def main():
         ref = O.forward(crops[:2], W.synthetic(1234), np.float64)
         ref_ang = np.stack([ref["yaw"], ref["pitch"], ref["roll"]], axis=1)
         got = d_ypr.cpu().numpy()[:2]
-        for y, a, l in outs[1:]:           # every engine produced the same bits
+        for y, a, l in outs[1:min(M, args.steps)]:       # every engine (that ran) produced the same bits
             assert torch.equal(y, d_ypr) and torch.equal(a, d_am) and torch.equal(l, d_lg), "in-flight forwards differ"
         out["check"] = {"max_abs_deg_vs_f64_oracle": float(np.abs(got - ref_ang).max()), "crops": 2}
     if rank == 0 and world == 1 and not args.no_latency:

@@ -10,10 +10,14 @@ for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE GRBM_GUI_ACTIVE" \
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAVES" \
-           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmc_${DT}_b${B}_p$i
   timeout 400 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $R/gpurun_out/pmc_${DT}_b${B}_p$i -o p -- $CMD > $R/gpurun_out/pmc_${DT}_b${B}_p$i.log 2>&1
-  echo "pmc pass $i ($PMC) exit $?"
+  rc=$?
+  # (exit 1 with a complete counter_collection.csv: the profiled command's own exit code -- see the log tail)
+  echo "pmc pass $i ($PMC) exit $rc; csv rows: $(cat $R/gpurun_out/pmc_${DT}_b${B}_p$i/*counter_collection.csv 2>/dev/null | wc -l)"
+  tail -3 $R/gpurun_out/pmc_${DT}_b${B}_p$i.log | cut -c1-300
 done
 ls $R/gpurun_out/pmc_${DT}_b${B}_p1

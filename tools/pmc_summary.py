@@ -70,6 +70,7 @@ def avg(a, name):
 
 print(f"{'kernel':52s}{'us':>7s} {'act%':>6s} {'valu%':>6s} {'lds%':>5s} {'wait%':>6s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'L2hit%':>6s} {'valu/wv':>8s} {'vmemRD/wv':>9s}")
 out = {}
+mfma_rows = []
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"]):
     wc = avg(a, "SQ_WAVE_CYCLES") or 1
     waves = avg(a, "SQ_WAVES") or 1
@@ -80,8 +81,21 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"]):
           f"{100 * avg(a, 'SQ_ACTIVE_INST_LDS') / wc:5.1f} {100 * avg(a, 'SQ_WAIT_ANY') / wc:6.1f} "
           f"{100 * avg(a, 'SQ_LDS_BANK_CONFLICT') / (avg(a, 'SQ_ACTIVE_INST_LDS') or 1):8.1f} {fetch / 1e6:8.2f} {write / 1e6:8.2f} "
           f"{100 * hit / ((hit + miss) or 1):6.1f} {avg(a, 'SQ_INSTS_VALU') / waves:8.0f} {avg(a, 'SQ_INSTS_VMEM_RD') / waves:9.1f}")
-    out[k] = {"dispatches_seen": a["tn"], "avg_us_under_pmc": a["t"] / max(a["tn"], 1), "hbm_bytes_per_launch": fetch + write,
+    busy_cu, mfma_busy = avg(a, "SQ_BUSY_CU_CYCLES"), avg(a, "SQ_VALU_MFMA_BUSY_CYCLES")
+    mfma_rows.append((k, a["t"] / max(a["tn"], 1), mfma_busy, avg(a, "SQ_INSTS_VALU_MFMA_MOPS_F16"), avg(a, "SQ_INSTS_MFMA"),
+                      busy_cu, avg(a, "GRBM_GUI_ACTIVE")))
+    out[k] = {"mfma_busy_cycles": mfma_busy, "busy_cu_cycles": busy_cu,
+              "mfma_util_of_busy_cu": (mfma_busy / (4 * busy_cu)) if busy_cu else None,
+              "dispatches_seen": a["tn"], "avg_us_under_pmc": a["t"] / max(a["tn"], 1), "hbm_bytes_per_launch": fetch + write,
               "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write}
+# Matrix-core occupancy per kernel (pass 6).  SQ_VALU_MFMA_BUSY_CYCLES counts cycles a SIMD's MFMA pipe is
+# busy (32 per v_mfma_f32_32x32x16_f16), summed over the chip; SQ_BUSY_CU_CYCLES counts cycles a CU has a wave,
+# summed over CUs; a CU has 4 SIMDs -> util = mfma_busy / (4 * busy_cu).
+if any(r[2] for r in mfma_rows):
+    print()
+    print(f"{'kernel':52s}{'us':>7s} {'mfma_busy':>11s} {'mops_f16':>10s} {'insts_mfma':>10s} {'busy_cu':>11s} {'util/busyCU%':>12s}")
+    for k, us, mb, mops, im, bc, gui in mfma_rows:
+        print(f"{k:52s}{us:7.1f} {mb:11.0f} {mops:10.0f} {im:10.0f} {bc:11.0f} {100 * mb / (4 * bc) if bc else 0:12.2f}")
 if len(sys.argv) > 2:
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 "
                        "(MI355X_MICROARCH.md HBM section: 64 B tallied per 128-B request on 16-B/lane streams; consistent "
