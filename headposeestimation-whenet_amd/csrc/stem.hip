@@ -101,20 +101,168 @@ __global__ __launch_bounds__(256) void whenet_stem_kernel(const uint8_t* __restr
     }
 }
 
+// ---- f16 configuration: the stem conv on the matrix cores ---------------------------------------
+// The scalar form above spends 864 FMAs per output pixel in the VALU (10.8 M per crop: the kernel was VALU-bound
+// at 3x its Swish floor).  Here the conv is a K = 27 contraction per pixel: k-step ky holds the 9 contiguous
+// (kx, ci) values of input row 2*oy + ky (padded to 16), weights are the MFMA A operand (32 out-channels),
+// 32 output pixels the B operand.  Inputs and weights are split x = hi + lo in binary16 and three products
+// (hi*hi, hi*lo, lo*hi) are accumulated in f32, so the result keeps ~22 bits: no accuracy is traded for the
+// matrix cores (the f16 rounding still happens once, at the output, as before).  9 MFMAs per 32-pixel strip.
+// Workgroup = crop x 4 output rows (14 strips over 4 waves); outputs are transposed through LDS so that every
+// lane stores 16 contiguous bytes of NHWC.
+constexpr int MR = 4;
+constexpr int MIN_ROWS = 2 * MR + 1;                 // 9
+constexpr int OPITCH = 40;                           // halfs per staged output pixel (80 B: 16-byte aligned)
+
+template <bool INF32>
+__global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __restrict__ in, half_t* __restrict__ out,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ lut) {
+    __shared__ float s_lut[3 * 256];
+    __shared__ __attribute__((aligned(16))) float s_img[MIN_ROWS * ROW_FLOATS];
+    __shared__ __attribute__((aligned(16))) half_t s_out[4][32 * OPITCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, lm = lane & 31;
+    const int oy0 = blockIdx.x * MR;
+    const int b = blockIdx.y;
+
+    // weight fragments (independent of the image: in flight while the rows are staged)
+    float wv[3][8];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 8 * g + e;
+            wv[ky][e] = (j < 9) ? w[(ky * 9 + j) * STEM_C + lm] : 0.0f;
+        }
+    float4v bv[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) bv[qq] = *reinterpret_cast<const float4v*>(bias + 8 * qq + 4 * g);
+
+    // the image rows are requested before anything is waited for: ONE global round trip per workgroup (the
+    // LUT, the weights and the rows travel together)
+    constexpr int NLD = (MIN_ROWS * ROW_DWORDS + 255) / 256;          // 6 dwords (or float4s) per lane
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in + size_t(b) * IMG * IMG * 3);
+    const float4v* inf = reinterpret_cast<const float4v*>(reinterpret_cast<const float*>(in) + size_t(b) * IMG * IMG * 3);
+    uint32_t raw[INF32 ? 1 : NLD];
+    float4v rawf[INF32 ? NLD : 1];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int d = tid + 256 * i;
+        const int r = d / ROW_DWORDS, j = d - r * ROW_DWORDS;
+        const int iy = 2 * oy0 + r;
+        const bool ok = d < MIN_ROWS * ROW_DWORDS && iy < IMG;
+        if constexpr (INF32) rawf[i] = ok ? inf[iy * ROW_DWORDS + j] : float4v{0.f, 0.f, 0.f, 0.f};
+        else raw[i] = ok ? in32[iy * ROW_DWORDS + j] : 0u;
+    }
+    if constexpr (!INF32)
+        for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = lut[i];
+    if (tid < MIN_ROWS * 4) s_img[(tid >> 2) * ROW_FLOATS + 672 + (tid & 3)] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int d = tid + 256 * i;
+        if (d >= MIN_ROWS * ROW_DWORDS) continue;
+        const int r = d / ROW_DWORDS, j = d - r * ROW_DWORDS;
+        const int iy = 2 * oy0 + r;
+        float* dst = &s_img[r * ROW_FLOATS + 4 * j];
+        if (INF32) {
+            dst[0] = rawf[i][0]; dst[1] = rawf[i][1]; dst[2] = rawf[i][2]; dst[3] = rawf[i][3];
+        } else if (iy < IMG) {
+            const uint32_t v = raw[i];
+            int ch = (4 * j) % 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dst[q] = s_lut[ch * 256 + ((v >> (8 * q)) & 0xff)];
+                ch = (ch == 2) ? 0 : ch + 1;
+            }
+        } else {          // bottom pad row (iy == 224): zero in the normalised domain
+            dst[0] = dst[1] = dst[2] = dst[3] = 0.0f;
+        }
+    }
+    half8 whi[3], wlo[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            whi[ky][e] = half_t(wv[ky][e]);
+            wlo[ky][e] = half_t(wv[ky][e] - float(whi[ky][e]));
+        }
+    __syncthreads();
+
+    constexpr int NSTRIP = MR * STEM_HW / 32;        // 14
+    half_t* so = s_out[wave];
+    half_t* obase = out + (size_t(b) * STEM_HW + oy0) * STEM_HW * STEM_C;
+    for (int strip = wave; strip < NSTRIP; strip += 4) {
+        const int p = strip * 32 + lm;
+        const int oyl = p / STEM_HW, ox = p - oyl * STEM_HW;
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = &s_img[(2 * oyl + ky) * ROW_FLOATS + ox * 6 + 8 * g];
+            float x[8];
+            if (g == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 v = *reinterpret_cast<const float2*>(row + 2 * i);     // (8-byte aligned: 24*ox)
+                    x[2 * i] = v.x;
+                    x[2 * i + 1] = v.y;
+                }
+            } else {
+                x[0] = row[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) x[i] = 0.0f;
+            }
+            half8 xhi, xlo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xhi[e] = half_t(x[e]);
+                xlo[e] = half_t(x[e] - float(xhi[e]));
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[ky], xhi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ky], xlo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ky], xhi, acc, 0, 0, 0);
+        }
+        // BN bias + Swish, one rounding to f16; lane holds channels 8*qq + 4*g + r of pixel lm
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            half4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = half_t(swish_f<false>(acc[4 * qq + r] + bv[qq][r]));
+            *reinterpret_cast<half4*>(so + lm * OPITCH + 8 * qq + 4 * g) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's own LDS region: no barrier needed)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lane + 64 * i;
+            const int px = idx >> 2, part = idx & 3;
+            const half8 v = *reinterpret_cast<const half8*>(so + px * OPITCH + part * 8);
+            *reinterpret_cast<half8*>(obase + size_t(strip * 32 + px) * STEM_C + part * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next strip overwrites
+    }
+}
+
 }  // namespace
 
 void launch_stem(const StemArgs& a, int dtype, hipStream_t stream) {
     dim3 grid(STEM_HW / ROWS_PER_BLOCK, a.n);
+    dim3 grid_m(STEM_HW / MR, a.n);
     if (a.in_f32 != nullptr) {
         const uint8_t* src = reinterpret_cast<const uint8_t*>(a.in_f32);
         if (dtype == WHENET_F16)
-            hipLaunchKernelGGL((whenet_stem_kernel<half_t, true>), grid, dim3(256), 0, stream, src,
+            hipLaunchKernelGGL((whenet_stem_mfma_kernel<true>), grid_m, dim3(256), 0, stream, src,
                                static_cast<half_t*>(a.out), a.w, a.bias, a.lut);
         else
             hipLaunchKernelGGL((whenet_stem_kernel<float, true>), grid, dim3(256), 0, stream, src,
                                static_cast<float*>(a.out), a.w, a.bias, a.lut);
     } else if (dtype == WHENET_F16)
-        hipLaunchKernelGGL((whenet_stem_kernel<half_t, false>), grid, dim3(256), 0, stream, a.in,
+        hipLaunchKernelGGL((whenet_stem_mfma_kernel<false>), grid_m, dim3(256), 0, stream, a.in,
                            static_cast<half_t*>(a.out), a.w, a.bias, a.lut);
     else
         hipLaunchKernelGGL((whenet_stem_kernel<float, false>), grid, dim3(256), 0, stream, a.in,
@@ -123,7 +271,7 @@ void launch_stem(const StemArgs& a, int dtype, hipStream_t stream) {
 }
 
 const char* kernel_name_stem(int dtype) {
-    return dtype == WHENET_F16 ? "whenet_stem_kernel<_Float16, false>" : "whenet_stem_kernel<float, false>";
+    return dtype == WHENET_F16 ? "whenet_stem_mfma_kernel<false>" : "whenet_stem_kernel<float, false>";
 }
 
 }  // namespace whenet
