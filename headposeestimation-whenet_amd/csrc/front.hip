@@ -109,8 +109,11 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         k.wf = wf0 + (k.tl * 64 + lane);
         return k;
     };
-    // PF k-steps of operands travel together (8 was measured: it spills at the 128-register budget of 4
-    // workgroups per CU and loses 25 %)
+    // PF k-steps of operands travel together.  Measured alternatives (B=64 and B=512, round 2): PF = 8 spills at
+    // the 128-register budget of 4 workgroups per CU (-25 %); PF = 8 with 168 registers, i.e. 3 workgroups per CU,
+    // is also 25 % slower although it saves a round trip per task; 5 waves per SIMD (96 registers) is neutral.
+    // Keeping the LDS tile E in f32 (no v_cvt_f32_f16 in the taps, -16 % VALU instructions) is 3-40 % SLOWER:
+    // the taps then read twice the LDS bytes.  The kernel sits on VALU issue with the LDS pipe half busy.
     constexpr int PF = 4;
     auto load_ops = [&](const Task& k, int ks, VT (&w)[PF], VT (&a)[PF]) {
 #pragma unroll
