@@ -93,12 +93,15 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
  *          "fuse_front" (0/1, default 1: expand 1x1 + depthwise as ONE kernel per block, the
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
- *          "trunk" (0/1, default 1: blocks 7..16 + head conv + heads as ONE persistent launch in which a
+ *          "trunk" (0/1, default 0: 1 = blocks 7..16 + head conv + heads as ONE persistent launch in which a
  *                  cluster of "trunk_c" workgroups (one per CU) processes a crop, splitting every layer's
- *                  channels and synchronising only inside the cluster; 0 = one launch per layer),
+ *                  channels and synchronising only inside the cluster; measured no faster than one launch
+ *                  per layer, kept as an option with its tests),
  *          "trunk_c" (1..16, default 4 for f16 / 8 for f32: workgroups per cluster; fixed per handle
  *                  because it fixes the summation order of the project convs),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
+ *          "lane_graphs" (0/1, default 0: 1 = one graph per lane launched on its own stream instead of
+ *                  one forked graph; measured equal),
  *          "inflight" (1..4, default 1: n > 1 gives the handle n engines -- own streams, activation
  *                  arena, graphs, replicated weights -- and spreads whenet_forward_u8_device calls with
  *                  stream == NULL and whenet_submit_* calls over them round-robin, each forward as
@@ -129,7 +132,12 @@ WHENET_API int whenet_forward_f32(whenet_t* h, const float* image, int n,
 /* Device-pointer form: all pointers are device memory on the handle's GPU; the work is
  * enqueued on `stream` (a hipStream_t; NULL = the handle's own stream, or with option "inflight"
  * > 1 the next of the handle's engines) and the call returns without waiting.  This is the form
- * bench.py times (inputs resident in HBM). */
+ * bench.py times (inputs resident in HBM).
+ * ORDERING: an engine has ONE activation arena, so two forwards of the same engine must not overlap.
+ * Calls with stream == NULL are ordered by the engine's own stream.  A caller that passes its own
+ * streams must order successive calls itself (same stream, or an event between them): the library does
+ * not insert cross-stream dependencies, and two forwards enqueued on different caller streams of one
+ * engine would race on the arena.  For concurrent forwards use option "inflight" (one arena per engine). */
 WHENET_API int whenet_forward_u8_device(whenet_t* h, const uint8_t* d_crops, int n,
                              float* d_ypr, int32_t* d_argmax, float* d_logits, void* stream);
 WHENET_API int whenet_sync(whenet_t* h);
