@@ -243,6 +243,18 @@ int whenet_op_crop_resize(whenet_t* h, const uint8_t* frame, int frame_h, int fr
     });
 }
 
+int whenet_yolo_eval(whenet_t* h, const float* const* feats, const int* grid_h, const int* grid_w, int num_layers,
+                     const float* anchors, int num_anchors, int num_classes, float image_h, float image_w,
+                     float score_threshold, float iou_threshold, int max_boxes, float* boxes, float* scores,
+                     int32_t* classes, int32_t* index, int* count, float* all_boxes, float* all_scores) {
+    if (count == nullptr) return WHENET_EINVAL;
+    return guarded(h, [&](whenet::Engine& e) {
+        *count = e.yolo_eval(feats, grid_h, grid_w, num_layers, anchors, num_anchors, num_classes, image_h, image_w,
+                             score_threshold, iou_threshold, max_boxes, boxes, scores, classes, index, all_boxes,
+                             all_scores);
+    });
+}
+
 int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argmax, float* logits) {
     return guarded(h, [&](whenet::Engine&) {
         const int idx = ticket % MAX_INFLIGHT_ENGINES;

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 
 namespace whenet {
@@ -993,6 +994,99 @@ void Engine::op_crop_resize(const uint8_t* frame, int fh, int fw, int swap_rb, c
         throw;
     }
     dev_free(d_frame); dev_free(d_plan); dev_free(d_out);
+}
+
+// yolo_eval (yolo_v3/model.py:193-232) on host feature maps: H2D, decode + NMS on the device, the selected boxes
+// back, concatenated class by class like the reference.  Returns the number of detections.
+int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* grid_w, int num_layers,
+                      const float* anchors, int num_anchors, int num_classes, float image_h, float image_w,
+                      float score_threshold, float iou_threshold, int max_boxes, float* boxes, float* scores,
+                      int32_t* classes, int32_t* index, float* all_boxes, float* all_scores) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(feats && grid_h && grid_w && anchors && boxes && scores && classes, WHENET_EINVAL,
+                   "yolo_eval: NULL argument");
+    WHENET_REQUIRE((num_layers == 3 && num_anchors == 9) || (num_layers == 2 && num_anchors == 6), WHENET_EINVAL,
+                   "yolo_eval: 3 maps with 9 anchors or 2 maps with 6 (model.py:203)");
+    WHENET_REQUIRE(num_classes >= 1 && num_classes <= 1024 && image_h > 0 && image_w > 0, WHENET_EINVAL,
+                   "yolo_eval: bad num_classes / image shape");
+    WHENET_REQUIRE(max_boxes >= 1 && max_boxes <= yolo_max_select(), WHENET_EINVAL, "yolo_eval: max_boxes must be 1..256");
+    // model.py:203: anchor_mask = [[6,7,8],[3,4,5],[0,1,2]] for 3 maps, [[3,4,5],[1,2,3]] for 2
+    static const int ANCHOR_MASK3[3][3] = {{6, 7, 8}, {3, 4, 5}, {0, 1, 2}};
+    static const int ANCHOR_MASK2[2][3] = {{3, 4, 5}, {1, 2, 3}};
+    YoloArgs a{};
+    a.num_layers = num_layers;
+    a.num_classes = num_classes;
+    a.na = 3;
+    a.input_h = float(grid_h[0] * 32);                    // model.py:204
+    a.input_w = float(grid_w[0] * 32);
+    a.image_h = image_h;
+    a.image_w = image_w;
+    {   // model.py:158-162, float32 like the graph: new_shape = round(image_shape * min(input_shape / image_shape))
+        const float ry = a.input_h / image_h, rx = a.input_w / image_w;
+        const float r = ry < rx ? ry : rx;
+        const float new_h = std::nearbyintf(image_h * r), new_w = std::nearbyintf(image_w * r);      // half to even
+        a.off_y = (a.input_h - new_h) / 2.0f / a.input_h;
+        a.off_x = (a.input_w - new_w) / 2.0f / a.input_w;
+        a.scale_y = a.input_h / new_h;
+        a.scale_x = a.input_w / new_w;
+    }
+    a.score_thr = score_threshold;
+    a.iou_thr = iou_threshold;
+    a.max_boxes = max_boxes;
+    TempBufs tmp;
+    int N = 0;
+    const size_t per = size_t(5 + num_classes) * 3;
+    for (int l = 0; l < num_layers; ++l) {
+        WHENET_REQUIRE(feats[l] && grid_h[l] > 0 && grid_w[l] > 0 && grid_h[l] <= 4096 && grid_w[l] <= 4096, WHENET_EINVAL,
+                       "yolo_eval: bad feature map");
+        YoloLayer& L = a.layer[l];
+        L.gh = grid_h[l];
+        L.gw = grid_w[l];
+        L.first = N;
+        for (int k = 0; k < 3; ++k) {
+            const int m = (num_layers == 3) ? ANCHOR_MASK3[l][k] : ANCHOR_MASK2[l][k];
+            L.anchor[k][0] = anchors[2 * m];
+            L.anchor[k][1] = anchors[2 * m + 1];
+        }
+        const size_t bytes = size_t(L.gh) * L.gw * per * sizeof(float);
+        float* d = static_cast<float*>(tmp.get(bytes));
+        WHENET_HIP_CHECK(hipMemcpyAsync(d, feats[l], bytes, hipMemcpyHostToDevice, stream_));
+        L.feats = d;
+        N += L.gh * L.gw * 3;
+    }
+    a.N = N;
+    a.NP = 1;
+    while (a.NP < N) a.NP <<= 1;
+    const size_t C = size_t(num_classes), MB = size_t(max_boxes);
+    a.boxes = static_cast<float*>(tmp.get(size_t(N) * 4 * sizeof(float)));
+    a.all_scores = all_scores ? static_cast<float*>(tmp.get(size_t(N) * C * sizeof(float))) : nullptr;
+    a.counts = static_cast<int*>(tmp.get(C * sizeof(int)));
+    a.keys = static_cast<unsigned long long*>(tmp.get(C * size_t(a.NP) * sizeof(unsigned long long)));
+    a.out_boxes = static_cast<float*>(tmp.get(C * MB * 4 * sizeof(float)));
+    a.out_scores = static_cast<float*>(tmp.get(C * MB * sizeof(float)));
+    a.out_index = static_cast<int*>(tmp.get(C * MB * sizeof(int)));
+    a.out_count = static_cast<int*>(tmp.get(C * sizeof(int)));
+    launch_yolo_eval(a, stream_);
+    std::vector<float> hb(C * MB * 4), hs(C * MB);
+    std::vector<int> hi(C * MB), hc(C);
+    WHENET_HIP_CHECK(hipMemcpyAsync(hb.data(), a.out_boxes, hb.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipMemcpyAsync(hs.data(), a.out_scores, hs.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipMemcpyAsync(hi.data(), a.out_index, hi.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipMemcpyAsync(hc.data(), a.out_count, hc.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (all_boxes)
+        WHENET_HIP_CHECK(hipMemcpyAsync(all_boxes, a.boxes, size_t(N) * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (all_scores)
+        WHENET_HIP_CHECK(hipMemcpyAsync(all_scores, a.all_scores, size_t(N) * C * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    int out = 0;                                          // model.py:227-229: concatenated class by class
+    for (size_t c = 0; c < C; ++c)
+        for (int k = 0; k < hc[c]; ++k, ++out) {
+            std::memcpy(boxes + size_t(out) * 4, hb.data() + (c * MB + size_t(k)) * 4, 4 * sizeof(float));
+            scores[out] = hs[c * MB + size_t(k)];
+            classes[out] = int32_t(c);
+            if (index) index[out] = hi[c * MB + size_t(k)];
+        }
+    return out;
 }
 
 // Per-launch timing of the forward AS THE TIMED PATH RUNS IT: the same sub-batch chains on the

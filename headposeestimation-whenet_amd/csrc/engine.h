@@ -81,6 +81,10 @@ class Engine {
     int profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap);
 
     void op_stem(const uint8_t* crops, int n, float* out);
+    int yolo_eval(const float* const* feats, const int* grid_h, const int* grid_w, int num_layers, const float* anchors,
+                  int num_anchors, int num_classes, float image_h, float image_w, float score_threshold,
+                  float iou_threshold, int max_boxes, float* boxes, float* scores, int32_t* classes, int32_t* index,
+                  float* all_boxes, float* all_scores);
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);

@@ -148,6 +148,34 @@ struct FrontArgs {
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);
 
+// ---- yolo.hip ---------------------------------------------------------------------------
+// YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.
+struct YoloLayer {
+    const float* feats;    // device [gh][gw][A*(5+C)]
+    int gh, gw;
+    int first;             // index of this layer's first box in the concatenated list
+    float anchor[3][2];    // (w, h) of the layer's anchors (anchor_mask applied)
+};
+struct YoloArgs {
+    YoloLayer layer[3];
+    int num_layers, num_classes, na;       // na = anchors per layer (3)
+    int N, NP;                             // boxes in total; key capacity per class (power of two >= N)
+    float input_h, input_w, image_h, image_w;
+    float off_y, off_x, scale_y, scale_x;  // letterbox correction (model.py:160-162), float32 as the graph computes it
+    float score_thr, iou_thr;
+    int max_boxes;
+    float* boxes;                          // [N][4] y_min, x_min, y_max, x_max
+    float* all_scores;                     // [N][C] or nullptr (tests)
+    int* counts;                           // [C]
+    unsigned long long* keys;              // [C][NP]
+    float* out_boxes;                      // [C][max_boxes][4]
+    float* out_scores;                     // [C][max_boxes]
+    int* out_index;                        // [C][max_boxes]
+    int* out_count;                        // [C]
+};
+void launch_yolo_eval(const YoloArgs& a, hipStream_t stream);
+int yolo_max_select();
+
 // ---- frame.hip --------------------------------------------------------------------------
 // Per-head pre-processing of a frame (demo_video.py:13-24): bbox margins -> crop window ->
 // (BGR->RGB) -> cv2.resize-compatible fixed-point bilinear to 224x224 uint8.

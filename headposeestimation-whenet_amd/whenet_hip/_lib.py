@@ -50,6 +50,8 @@ _PROTOS = {
     "whenet_frame_rects": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P]),
     "whenet_submit_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_crop_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "whenet_yolo_eval": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
     "whenet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
     "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
@@ -250,6 +252,44 @@ class Handle:
         self._check(self._lib.whenet_op_crop_resize(self._h, _ptr(frame), frame.shape[0], frame.shape[1],
                                                     BGR if bgr else RGB, _ptr(rects), rects.shape[0], _ptr(out)))
         return out
+
+    def yolo_eval(self, yolo_outputs, anchors, num_classes: int, image_shape, max_boxes: int = 20,
+                  score_threshold: float = .6, iou_threshold: float = .5, debug: bool = False):
+        """yolo_v3/model.py:193-232 on numpy feature maps [gh, gw, 3*(5+C)] (or with a leading batch axis of 1).
+        Returns boxes [k,4] (y_min, x_min, y_max, x_max), scores [k], classes [k]; with debug also the box
+        indices and every decoded box / score."""
+        maps = []
+        for m in yolo_outputs:
+            m = np.asarray(m)
+            if m.ndim == 4:
+                if m.shape[0] != 1:
+                    raise ValueError("yolo_eval: batch of one, as YOLO.detect feeds it")
+                m = m[0]
+            if m.ndim != 3 or m.shape[2] != 3 * (5 + num_classes):
+                raise ValueError(f"yolo_eval: feature map of shape {m.shape}, expected [gh, gw, {3 * (5 + num_classes)}]")
+            maps.append(np.ascontiguousarray(m, np.float32))
+        anchors = np.ascontiguousarray(anchors, np.float32).reshape(-1, 2)
+        L = len(maps)
+        ptrs = (_P * L)(*[_ptr(m) for m in maps])
+        gh = np.array([m.shape[0] for m in maps], np.int32)
+        gw = np.array([m.shape[1] for m in maps], np.int32)
+        n_all = int(sum(m.shape[0] * m.shape[1] * 3 for m in maps))
+        cap = num_classes * max_boxes
+        boxes = np.empty((cap, 4), np.float32)
+        scores = np.empty(cap, np.float32)
+        classes = np.empty(cap, np.int32)
+        index = np.empty(cap, np.int32)
+        all_boxes = np.empty((n_all, 4), np.float32) if debug else None
+        all_scores = np.empty((n_all, num_classes), np.float32) if debug else None
+        count = C.c_int(0)
+        self._check(self._lib.whenet_yolo_eval(self._h, ptrs, _ptr(gh), _ptr(gw), L, _ptr(anchors), anchors.shape[0],
+                                               num_classes, float(image_shape[0]), float(image_shape[1]),
+                                               float(score_threshold), float(iou_threshold), int(max_boxes), _ptr(boxes),
+                                               _ptr(scores), _ptr(classes), _ptr(index), C.byref(count), _ptr(all_boxes),
+                                               _ptr(all_scores)))
+        k = count.value
+        res = (boxes[:k].copy(), scores[:k].copy(), classes[:k].copy())
+        return res + (index[:k].copy(), all_boxes, all_scores) if debug else res
 
     def collect(self, ticket: int, n: int, want_logits: bool = False):
         ypr = np.empty((n, 3), np.float32)

@@ -59,3 +59,33 @@ def head_boxes(k: int, h: int = 720, w: int = 1280, seed: int = 11) -> np.ndarra
     cy = rng.uniform(0.0, 1.0, k) * (h - size)
     cx = rng.uniform(0.0, 1.0, k) * (w - size * 0.8)
     return np.stack([cy, cx, cy + size, cx + size * 0.8], axis=1).astype(np.float32)
+
+
+# yolo_v3/data/yolo_anchors.txt of the reference (w,h pairs, 9 anchors -> three output maps)
+YOLO_ANCHORS = np.array([10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326], np.float32).reshape(-1, 2)
+
+
+def yolo_maps(seed: int, num_classes: int = 1, grid: int = 13, objects: int = 10, num_layers: int = 3):
+    """Seeded stand-ins for the detector's output maps ([g,g,3*(5+C)], [2g,2g,..], [4g,4g,..], float32, coarsest
+    first): low-confidence background plus `objects` planted detections, each repeated on neighbouring cells /
+    anchors with slightly different offsets so that NMS has overlapping candidates to suppress."""
+    rng = np.random.default_rng(seed)
+    maps = []
+    for l in range(num_layers):
+        g = grid << l
+        m = rng.normal(0.0, 1.0, (g, g, 3, 5 + num_classes)).astype(np.float32)
+        m[..., 4] = rng.normal(-7.0, 1.5, (g, g, 3))                   # background confidence logits
+        for _ in range(objects):
+            y, x, a = int(rng.integers(1, g - 1)), int(rng.integers(1, g - 1)), int(rng.integers(0, 3))
+            c = int(rng.integers(0, num_classes))
+            for dy, dx, da in ((0, 0, 0), (0, 1, 0), (1, 0, 0), (0, 0, 1), (-1, 0, 2)):
+                if rng.random() < 0.7 or (dy, dx, da) == (0, 0, 0):
+                    yy, xx, aa = y + dy, x + dx, (a + da) % 3
+                    t = m[yy, xx, aa]
+                    t[0:2] = rng.normal(0.0, 0.6, 2) - 2.0 * np.array([dx, dy])     # pulls the centre back towards (x, y)
+                    t[2:4] = rng.normal(0.0, 0.25, 2)
+                    t[4] = rng.normal(3.0, 1.5)
+                    t[5:] = rng.normal(-3.0, 1.0, num_classes)
+                    t[5 + c] = rng.normal(3.0, 1.0)
+        maps.append(m.reshape(g, g, 3 * (5 + num_classes)))
+    return maps

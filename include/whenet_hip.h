@@ -174,6 +174,25 @@ WHENET_API int whenet_submit_frame(whenet_t* h, const uint8_t* frame, int frame_
 WHENET_API int whenet_op_crop_resize(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
                           const int32_t* rects, int k, uint8_t* crops);
 
+/* ---- the detector's post-processing on the device: replaces yolo_eval (yolo_v3/model.py:193-232 =
+ * yolo_head :125-150, yolo_correct_boxes :153-178, yolo_boxes_and_scores :181-190, per-class
+ * tf.image.non_max_suppression), which the reference runs inside sess.run (yolo_postprocess.py:198-204).
+ *   feats        num_layers host pointers to the detector's output maps, float32 [grid_h][grid_w][3*(5+num_classes)]
+ *                (batch of one, as YOLO.detect feeds it), coarsest map first like the Keras model's outputs
+ *   anchors      num_anchors x (w, h) as in yolo_anchors.txt; 3 maps need 9 anchors, 2 maps ("tiny") 6
+ *   image_h/w    size of the original image (`input_image_shape`); the network input is 32 x the first map's grid
+ *   max_boxes    per class, 1..256 (reference default 20); score: `>= score_threshold`; NMS drops IoU `> iou_threshold`
+ *   boxes        float [num_classes*max_boxes][4]  y_min, x_min, y_max, x_max in image pixels (not clipped, as the reference)
+ *   scores, classes, index (may be NULL: the box's position in the concatenated (map, y, x, anchor) list)
+ *   count        number of detections written, class by class, descending score inside a class
+ *   all_boxes [N][4], all_scores [N][num_classes] (may be NULL): every decoded box / score, for tests
+ * Equal scores are taken lower index first (TensorFlow leaves ties to its heap). */
+WHENET_API int whenet_yolo_eval(whenet_t* h, const float* const* feats, const int* grid_h, const int* grid_w,
+                     int num_layers, const float* anchors, int num_anchors, int num_classes, float image_h,
+                     float image_w, float score_threshold, float iou_threshold, int max_boxes, float* boxes,
+                     float* scores, int32_t* classes, int32_t* index, int* count, float* all_boxes,
+                     float* all_scores);
+
 /* ---- measurement: run `iters` eager forwards of `n` device-resident crops exactly as the
  * timed path runs them (same concurrent sub-batch chains, same streams) with ONE HIP event
  * recorded on the chain's stream between consecutive kernel launches; a launch's time is
