@@ -30,6 +30,7 @@ Extra objects on the line:
   latency_b1    configs[1]: batch=1 fp32 single-crop latency (median / p99), N=1 only
   frame_pipeline  configs[4]: one video frame + k head boxes per submission (PCIe included), N=1 only
   pcie_inclusive  the host-pointer forms on the same batch, H2D + D2H included (never `value`)
+  yolo_postprocess  §8f row 4: whenet_yolo_eval on one 416x416 detector output, per call, host to host
   serial_schedule the timed region with one forward at a time (also as top-level `value_serial` /
                 `ms_per_step_serial`)
   config.per_rank_crops_s / world_size / backend   what each rank did on its own clock, the RCCL world
@@ -219,6 +220,29 @@ def host_leg(h, crops):
     return {"batch": B, "dtype": "f16", "forward_u8_blocking_crops_s": blocking,
             "submit_collect_3_in_flight_crops_s": piped,
             "note": "host uint8 crops in, angles out; H2D 9.6 MB per batch of 64 over PCIe included"}
+
+
+def yolo_leg(h):
+    """yolo_eval (yolo_v3/model.py:193-232) for one 416x416 detector output (10,647 boxes, one
+    class), host maps in -> detections out (H2D of 255 KB included), next to the numpy restatement on the host."""
+    from whenet_hip import synth
+    from oracle import yolo_oracle as Y
+    maps = synth.yolo_maps(1, num_classes=1)
+    kw = dict(max_boxes=20, score_threshold=0.3, iou_threshold=0.45)
+    for _ in range(5):
+        got = h.yolo_eval(maps, synth.YOLO_ANCHORS, 1, (720, 1280), **kw)
+    lat = []
+    for _ in range(200):
+        a = time.perf_counter()
+        h.yolo_eval(maps, synth.YOLO_ANCHORS, 1, (720, 1280), **kw)
+        lat.append(time.perf_counter() - a)
+    a = time.perf_counter()
+    for _ in range(3):
+        ref = Y.yolo_eval(maps, synth.YOLO_ANCHORS, 1, (720, 1280), **kw)
+    cpu = (time.perf_counter() - a) / 3
+    return {"boxes": 10647, "detections": int(len(got[0])), "same_count_as_numpy": bool(len(got[0]) == len(ref[0])),
+            "gpu_median_us": float(np.median(lat) * 1e6), "numpy_port_us": cpu * 1e6,
+            "note": "blocking whenet_yolo_eval per frame: H2D of the three maps, decode + NMS kernels, D2H"}
 
 
 def main():
@@ -445,6 +469,7 @@ def main():
         out["frame_pipeline"] = frame_leg(h)
         # PCIe-inclusive rates of the host-pointer forms on the same batch (never `value`)
         out["pcie_inclusive"] = host_leg(h, crops)
+        out["yolo_postprocess"] = yolo_leg(h)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     h.close()
