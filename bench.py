@@ -474,6 +474,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     h.close()
     if rank == 0:
+        try:                      # RCCL's version banner sits in the C stdio buffer: push it out first, so that the
+            import ctypes         # JSON line is the LAST line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
