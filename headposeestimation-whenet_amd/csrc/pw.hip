@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                                                              int NCH) {
     constexpr int V = Vec<T>::V;
     using VT = typename Vec<T>::type;
-    constexpr int UK = 4;                                   // k-steps per LDS stage
+    constexpr int UK = 4;                                   // k-steps per LDS stage (8: measured -3 % on the K = 32..96 layers)
     constexpr int STAGE_VECS = UK * NT * 64;                // 16-byte vectors per stage
     constexpr int CPT = (STAGE_VECS + 255) / 256;           // staging copies per lane
     constexpr int SW = IsF32<T>::value ? 32 : 64;           // epilogue stage width: 128-byte output rows
