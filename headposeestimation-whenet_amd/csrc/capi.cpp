@@ -274,6 +274,10 @@ int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int iters, whenet
     });
 }
 
+int whenet_op_stem_dw(whenet_t* h, const uint8_t* crops, int n, float* dw_out, float* sums) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_stem_dw(crops, n, dw_out, sums); });
+}
+
 int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* out) {
     return guarded(h, [&](whenet::Engine& e) { e.op_stem(crops, n, out); });
 }

@@ -215,6 +215,10 @@ void Engine::set_option(const std::string& key, long value) {
         lanes_ = int(value);
         sync();
         drop_graphs();
+    } else if (key == "fuse_stem") {
+        fuse_stem_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "lane_graphs") {
         lane_graphs_ = value != 0;
         sync();
@@ -256,6 +260,7 @@ void Engine::get_info(whenet_info_t* out) const {
             k += 2;
         }
         if (trunk_) k = k - 2 + 1;
+        if (fuse_stem_ && dtype_ == WHENET_F16 && pw_impl_ == 0) k -= 1;     // option: stem + block 1's depthwise as one launch
         out->n_kernels_per_forward = k;
     }
     out->macs_per_crop = 384857312;
@@ -354,7 +359,7 @@ struct Rec {
 }  // namespace
 
 void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                           LaunchRecorder* rec) {
+                           LaunchRecorder* rec, bool dw_done) {
     Rec R{rec, s, repeat_};
     const BlockSpec& sp = b.spec;
     const std::string p = "b" + std::to_string(sp.index);
@@ -362,7 +367,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const int hw_in = sp.h_in * sp.h_in, hw_out = sp.h_out * sp.h_out;
     const int cexp = sp.cexp();
     const void* dw_in = in;
-    int se_ntiles = b.dw.plan.ntiles();
+    int se_ntiles = dw_done ? stem_dw_bands() : b.dw.plan.ntiles();     // (dw_done: stemdw.hip wrote v.d and its band sums)
     const bool fused = fuse_front_ && sp.has_expand() && pw_impl_ == 0;
     bool se_in_front = false;
     if (fused) {
@@ -411,7 +416,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
         dw_in = v.e;
     }
-    if (!fused) {
+    if (!fused && !dw_done) {
         DwArgs a{};
         a.in = dw_in;
         a.out = v.d;
@@ -571,7 +576,15 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
                              hipStream_t s, LaunchRecorder* rec, const float* d_in_f32, bool front_only) {
     Rec R{rec, s, repeat_};
     const double es = double(esz());
-    {
+    // f16, uint8 input: the stem and block 1's depthwise conv are one row-streaming launch (stemdw.hip); the stem
+    // output never reaches HBM, block 1 starts at its squeeze-excite
+    const bool stem_dw = fuse_stem_ && dtype_ == WHENET_F16 && d_in_f32 == nullptr && pw_impl_ == 0;
+    if (stem_dw) {
+        const DevBlock& b1 = blocks_[0];
+        StemDwArgs a{d_in, v.d, v.partial, d_stem_w_, d_stem_b_, d_lut_, b1.dw.w, b1.dw.bias, n};
+        R("stem+b1/dw", "stem", kernel_name_stem_dw(), double(n) * (IN_BYTES + X_ELEMS * es),
+          2.0 * n * (10838016.0 + 9.0 * X_ELEMS), [&] { launch_stem_dw(a, s); });
+    } else {
         StemArgs a{d_in, v.x0, d_stem_w_, d_stem_b_, d_lut_, n};
         a.in_f32 = d_in_f32;
         R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
@@ -581,7 +594,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
     const size_t nlayer = trunk_ ? 6 : blocks_.size();
     for (size_t i = 0; i < nlayer; ++i) {
         void* nxt = (cur == v.x0) ? v.x1 : v.x0;
-        enqueue_block(blocks_[i], v, cur, nxt, n, s, rec);
+        enqueue_block(blocks_[i], v, cur, nxt, n, s, rec, stem_dw && i == 0);
         cur = nxt;
     }
     if (trunk_) {
@@ -1182,6 +1195,26 @@ void Engine::op_stem(const uint8_t* crops, int n, float* out) {
     launch_stem(a, dtype_, stream_);
     launch_act_to_f32(x0_, d_out, N * X_ELEMS, dtype_, stream_);
     WHENET_HIP_CHECK(hipMemcpyAsync(out, d_out, N * X_ELEMS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// f16 only: the fused stem + block-1 depthwise launch on host crops; dw_out [n,112,112,32] as f32, sums [n][bands][32]
+void Engine::op_stem_dw(const uint8_t* crops, int n, float* dw_out, float* sums) {
+    DeviceGuard guard(device_);
+    WHENET_REQUIRE(crops && dw_out, WHENET_EINVAL, "op_stem_dw: NULL argument");
+    WHENET_REQUIRE(dtype_ == WHENET_F16, WHENET_EINVAL, "op_stem_dw: the fused launch exists for the f16 configuration only");
+    ensure_capacity(n);
+    TempBufs tmp;
+    const size_t N = size_t(n);
+    float* d_out = static_cast<float*>(tmp.get(N * X_ELEMS * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
+    StemDwArgs a{in_u8_, d_, partial_, d_stem_w_, d_stem_b_, d_lut_, blocks_[0].dw.w, blocks_[0].dw.bias, n};
+    launch_stem_dw(a, stream_);
+    launch_act_to_f32(d_, d_out, N * X_ELEMS, dtype_, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(dw_out, d_out, N * X_ELEMS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (sums)
+        WHENET_HIP_CHECK(hipMemcpyAsync(sums, partial_, N * size_t(stem_dw_bands()) * 32 * sizeof(float),
+                                        hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 

@@ -85,6 +85,7 @@ class Engine {
                   int num_anchors, int num_classes, float image_h, float image_w, float score_threshold,
                   float iou_threshold, int max_boxes, float* boxes, float* scores, int32_t* classes, int32_t* index,
                   float* all_boxes, float* all_scores);
+    void op_stem_dw(const uint8_t* crops, int n, float* dw_out, float* sums);
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
@@ -133,7 +134,7 @@ class Engine {
                          hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr, bool front_only = false);
     const void* block6_out(const View& v) const { return v.x0; }      // 6 blocks from x0: x0 -> x1 -> ... -> x0
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                       LaunchRecorder* rec);
+                       LaunchRecorder* rec, bool dw_done = false);
     TrunkArgs trunk_args(const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr, int32_t* d_amax,
                          float* dump_x);
     void ensure_trunk();
@@ -157,6 +158,8 @@ class Engine {
     int pw_impl_ = 0;
     int repeat_ = 1;
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
+    bool fuse_stem_ = false;    // option "fuse_stem": f16, uint8 input: stem + block 1's depthwise as one kernel (stemdw.hip);
+                                // measured: +1 % at 512 crops, equal at 64, 35 us WORSE at batch 1 (7 serial workgroups per crop)
     bool trunk_ = false;        // option "trunk": blocks 7..16 + head + heads as ONE persistent launch, a cluster of
                                 // trunk_c_ workgroups per crop (trunk.hip).  Correct and tested; measured slower than
                                 // one launch per layer at every batch size, so it is off by default

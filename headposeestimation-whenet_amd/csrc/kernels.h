@@ -148,6 +148,23 @@ struct FrontArgs {
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);
 
+// ---- stemdw.hip -------------------------------------------------------------------------
+// f16 configuration, uint8 input: stem + block 1's depthwise conv as one row-streaming kernel.
+struct StemDwArgs {
+    const uint8_t* in;     // [n,224,224,3]
+    void* out;             // [n,112,112,32] half: block 1's depthwise output
+    float* partial;        // [n][stem_dw_bands()][32] channel sums of that output per band
+    const float* w;        // stem [27][32]
+    const float* bias;     // stem [32]
+    const float* lut;      // [3][256]
+    const float* wd;       // block 1 depthwise [9][32]
+    const float* bd;       // [32]
+    int n;
+};
+void launch_stem_dw(const StemDwArgs& a, hipStream_t stream);
+int stem_dw_bands();
+const char* kernel_name_stem_dw();
+
 // ---- yolo.hip ---------------------------------------------------------------------------
 // YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.
 struct YoloLayer {

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void whenet_stem_kernel(const uint8_t* __restr
 // (kx, ci) values of input row 2*oy + ky (padded to 16), weights are the MFMA A operand (32 out-channels),
 // 32 output pixels the B operand.  Inputs and weights are split x = hi + lo in binary16 and three products
 // (hi*hi, hi*lo, lo*hi) are accumulated in f32, so the result keeps ~22 bits: no accuracy is traded for the
-// matrix cores (the f16 rounding still happens once, at the output, as before).  9 MFMAs per 32-pixel strip.
+// matrix cores; the LUT and the staged rows hold the pair packed in one dword, so building a fragment is two
+// permutes per two pixels' values instead of conversions (the f16 rounding still happens once, at the output, as before).  9 MFMAs per 32-pixel strip.
 // Workgroup = crop x 4 output rows (14 strips over 4 waves); outputs are transposed through LDS so that every
 // lane stores 16 contiguous bytes of NHWC.
 constexpr int MR = 4;
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ lut) {
-    __shared__ float s_lut[3 * 256];
-    __shared__ __attribute__((aligned(16))) float s_img[MIN_ROWS * ROW_FLOATS];
+    __shared__ uint32_t s_lut[3 * 256];          // the normalisation LUT as packed binary16 (hi | lo << 16): v = hi + lo
+    __shared__ __attribute__((aligned(16))) uint32_t s_img[MIN_ROWS * ROW_FLOATS];     // staged rows, packed the same way
     __shared__ __attribute__((aligned(16))) half_t s_out[4][32 * OPITCH];
 
     const int tid = threadIdx.x;
@@ -158,9 +159,13 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
         if constexpr (INF32) rawf[i] = ok ? inf[iy * ROW_DWORDS + j] : float4v{0.f, 0.f, 0.f, 0.f};
         else raw[i] = ok ? in32[iy * ROW_DWORDS + j] : 0u;
     }
+    auto pack = [](float v) -> uint32_t {
+        const half_t hi = half_t(v), lo = half_t(v - float(hi));
+        return uint32_t(__builtin_bit_cast(unsigned short, hi)) | (uint32_t(__builtin_bit_cast(unsigned short, lo)) << 16);
+    };
     if constexpr (!INF32)
-        for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = lut[i];
-    if (tid < MIN_ROWS * 4) s_img[(tid >> 2) * ROW_FLOATS + 672 + (tid & 3)] = 0.0f;
+        for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = pack(lut[i]);
+    if (tid < MIN_ROWS * 4) s_img[(tid >> 2) * ROW_FLOATS + 672 + (tid & 3)] = 0u;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -168,9 +173,9 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
         if (d >= MIN_ROWS * ROW_DWORDS) continue;
         const int r = d / ROW_DWORDS, j = d - r * ROW_DWORDS;
         const int iy = 2 * oy0 + r;
-        float* dst = &s_img[r * ROW_FLOATS + 4 * j];
+        uint32_t* dst = &s_img[r * ROW_FLOATS + 4 * j];
         if (INF32) {
-            dst[0] = rawf[i][0]; dst[1] = rawf[i][1]; dst[2] = rawf[i][2]; dst[3] = rawf[i][3];
+            dst[0] = pack(rawf[i][0]); dst[1] = pack(rawf[i][1]); dst[2] = pack(rawf[i][2]); dst[3] = pack(rawf[i][3]);
         } else if (iy < IMG) {
             const uint32_t v = raw[i];
             int ch = (4 * j) % 3;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
                 ch = (ch == 2) ? 0 : ch + 1;
             }
         } else {          // bottom pad row (iy == 224): zero in the normalised domain
-            dst[0] = dst[1] = dst[2] = dst[3] = 0.0f;
+            dst[0] = dst[1] = dst[2] = dst[3] = 0u;
         }
     }
     half8 whi[3], wlo[3];
@@ -204,26 +209,29 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const float* row = &s_img[(2 * oyl + ky) * ROW_FLOATS + ox * 6 + 8 * g];
-            float x[8];
+            // 8 packed (hi | lo << 16) values of this lane's k-group -> the hi and the lo fragment (2 permutes per pair)
+            const uint32_t* row = &s_img[(2 * oyl + ky) * ROW_FLOATS + ox * 6 + 8 * g];
+            uint32_t d[8];
             if (g == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float2 v = *reinterpret_cast<const float2*>(row + 2 * i);     // (8-byte aligned: 24*ox)
-                    x[2 * i] = v.x;
-                    x[2 * i + 1] = v.y;
+                    const uint2 v = *reinterpret_cast<const uint2*>(row + 2 * i);     // (8-byte aligned: 24*ox)
+                    d[2 * i] = v.x;
+                    d[2 * i + 1] = v.y;
                 }
             } else {
-                x[0] = row[0];
+                d[0] = row[0];
 #pragma unroll
-                for (int i = 1; i < 8; ++i) x[i] = 0.0f;
+                for (int i = 1; i < 8; ++i) d[i] = 0u;
             }
-            half8 xhi, xlo;
+            uint32_t ph[4], pl[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xhi[e] = half_t(x[e]);
-                xlo[e] = half_t(x[e] - float(xhi[e]));
+            for (int i = 0; i < 4; ++i) {
+                ph[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
+                pl[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
             }
+            const half8 xhi = __builtin_bit_cast(half8, uint4{ph[0], ph[1], ph[2], ph[3]});
+            const half8 xlo = __builtin_bit_cast(half8, uint4{pl[0], pl[1], pl[2], pl[3]});
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[ky], xhi, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ky], xlo, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[ky], xhi, acc, 0, 0, 0);

@@ -54,6 +54,7 @@ _PROTOS = {
                                    C.c_float, C.c_float, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
     "whenet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
+    "whenet_op_stem_dw": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "whenet_op_head": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "whenet_op_trunk": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
@@ -340,6 +341,13 @@ class Handle:
         out = np.empty((n, 112, 112, 32), np.float32)
         self._check(self._lib.whenet_op_stem(self._h, _ptr(crops), n, _ptr(out)))
         return out
+
+    def op_stem_dw(self, crops: np.ndarray):
+        n = crops.shape[0]
+        dw = np.empty((n, 112, 112, 32), np.float32)
+        sums = np.empty((n, 7, 32), np.float32)
+        self._check(self._lib.whenet_op_stem_dw(self._h, _ptr(crops), n, _ptr(dw), _ptr(sums)))
+        return dw, sums
 
     def op_block(self, index: int, x: np.ndarray):
         from . import spec

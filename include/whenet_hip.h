@@ -99,6 +99,9 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  per layer, kept as an option with its tests),
  *          "trunk_c" (1..16, default 4 for f16 / 8 for f32: workgroups per cluster; fixed per handle
  *                  because it fixes the summation order of the project convs),
+ *          "fuse_stem" (0/1, default 0: f16 configuration, uint8 input: stem + block 1's depthwise conv as ONE
+ *                  row-streaming launch, the stem output stays in LDS; measured +1 % at 512 crops, equal at 64,
+ *                  35 us slower at batch 1, so it is an option),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "lane_graphs" (0/1, default 0: 1 = one graph per lane launched on its own stream instead of
  *                  one forked graph; measured equal),
@@ -208,6 +211,9 @@ WHENET_API int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int it
  * shape.  Any output pointer may be NULL. */
 /* stem: normalise + Conv3x3/s2 + BN + Swish.  out [n,112,112,32] */
 WHENET_API int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* out);
+/* f16 configuration: stem + block 1's depthwise conv as the one launch the forward uses (stemdw.hip):
+ * dw_out float [n,112,112,32] (block 1's depthwise output), sums float [n][7][32] per-band channel sums (may be NULL) */
+WHENET_API int whenet_op_stem_dw(whenet_t* h, const uint8_t* crops, int n, float* dw_out, float* sums);
 /* MBConv block `index` (1..16) on input [n,H,W,Cin]:
  *   expand_out [n,H,W,Cexp] (NULL for block 1), dw_out [n,Ho,Wo,Cexp], gate [n,Cexp],
  *   out [n,Ho,Wo,Cout] (after project + BN + skip) */

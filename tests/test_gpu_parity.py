@@ -72,7 +72,8 @@ def test_info(handle):
     i = handle.info()
     assert i.abi_version == _lib.ABI_VERSION
     assert (i.params_backbone, i.params_heads, i.n_tensors) == (4_049_564, 322_812, 315)
-    # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads  (20 with option trunk=1: blocks 7..16 + head as one launch)
+    # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads  (20 with option trunk=1: blocks 7..16 + head as one
+    # launch; one less with option fuse_stem=1 in the f16 configuration)
     assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 51
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
@@ -252,6 +253,51 @@ def test_mfma_against_scalar_check_kernels(handle, golden):
     finally:
         handle.set_option("pw_impl", 0)
     assert np.abs(lg0 - lg1).max() < (2e-3 if handle.name == "f32" else 0.5)
+
+
+def test_fused_stem_dw_against_the_two_launches(golden):
+    """f16, option fuse_stem=1: stem + block 1's depthwise conv as one row-streaming launch (stemdw.hip) against the
+    two separate launches (the default).  Both convs use the same operands and summation order, so block 1's
+    depthwise output is the same up to a few f16 rounding flips; the grouping of the squeeze-excite partial sums
+    differs (bands instead of tiles).  Behind 16 blocks that is f16 noise on the logits."""
+    h = _lib.Handle(W.pack(W.synthetic(1234)), device=0, dtype=_lib.F16)
+    try:
+        crops = np.concatenate([golden["crops"], synth.noise_crops(9, seed=3)])      # 17 crops: every band, ragged
+        y0, a0, l0 = h.forward(crops)
+        assert h.info().n_kernels_per_forward == 51
+        h.set_option("fuse_stem", 1)
+        y1, a1, l1 = h.forward(crops)
+        assert h.info().n_kernels_per_forward == 50
+        assert np.abs(l1 - l0).max() < 0.5 and np.abs(y1 - y0).max() < 0.3
+        assert (a1 != a0).sum() <= 2
+        # batch invariance holds inside the option too
+        y2, a2, l2 = h.forward(crops[5:6])
+        assert np.array_equal(l2[0], l1[5])
+        # real-valued crops have no byte LUT: they take the separate launches in either setting
+        x = ((crops[:3] / 255 - np.array([0.485, 0.456, 0.406])) / np.array([0.229, 0.224, 0.225])).astype(np.float32)
+        yf, _, lf = h.forward_f32(x)
+        assert np.abs(lf - l0[:3]).max() < 0.5
+    finally:
+        h.close()
+
+
+def test_fused_stem_dw_kernel(golden, taps):
+    """The fused launch alone: block 1's depthwise output against the oracle and against the two separate kernels
+    (same operands, same summation order: equal up to f16 rounding flips), and its per-band channel sums."""
+    h = _lib.Handle(W.pack(W.synthetic(1234)), device=0, dtype=_lib.F16)
+    try:
+        crops = taps["crops"]
+        dw, sums = h.op_stem_dw(crops)
+        ref = taps["b1/dw"]
+        assert rel_err(dw, ref) < 2e-2            # (chained on the kernel's own f16 stem rows)
+        two = h.op_block(1, h.op_stem(crops))["dw"]
+        d = np.abs(dw - two)
+        assert d.max() <= 2.0 ** -8 * max(1.0, np.abs(two).max()) and (d > 0).mean() < 1e-3
+        assert np.allclose(sums.sum(axis=1), ref.sum(axis=(1, 2)), rtol=2e-3, atol=2.0)
+        # bands: rows 16*i .. 16*i + 15
+        assert np.allclose(sums[:, 3], ref[:, 48:64].sum(axis=(1, 2)), rtol=2e-3, atol=1.0)
+    finally:
+        h.close()
 
 
 def test_batch_invariance_and_permutation(handle, golden):
