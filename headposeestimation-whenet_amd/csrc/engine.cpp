@@ -170,7 +170,7 @@ Engine::~Engine() {
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_};
+    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, hcount_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
@@ -213,6 +213,10 @@ void Engine::set_option(const std::string& key, long value) {
     } else if (key == "lanes") {
         WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "lanes must be 1..8");
         lanes_ = int(value);
+        sync();
+        drop_graphs();
+    } else if (key == "split_heads") {
+        split_heads_ = value != 0;
         sync();
         drop_graphs();
     } else if (key == "fuse_stem") {
@@ -280,7 +284,7 @@ void Engine::drop_graphs() {
 }
 
 void Engine::release_arena() {
-    void** arena[] = {&x0_, &x1_, &e_, &d_, &hc_, reinterpret_cast<void**>(&partial_), reinterpret_cast<void**>(&gate_),
+    void** arena[] = {&x0_, &x1_, &e_, &d_, &hc_, reinterpret_cast<void**>(&partial_), reinterpret_cast<void**>(&gate_), reinterpret_cast<void**>(&hcount_),
                       reinterpret_cast<void**>(&in_u8_), reinterpret_cast<void**>(&o_ypr_),
                       reinterpret_cast<void**>(&o_amax_), reinterpret_cast<void**>(&o_logits_)};
     for (void** p : arena) {
@@ -316,6 +320,8 @@ void Engine::ensure_capacity(int n) {
     hc_ = alloc(N * HC_ELEMS * es);
     partial_ = static_cast<float*>(alloc(N * partial_per_crop_ * sizeof(float)));
     gate_ = static_cast<float*>(alloc(N * 1152 * sizeof(float)));
+    hcount_ = static_cast<unsigned*>(alloc(N * sizeof(unsigned)));
+    WHENET_HIP_CHECK(hipMemset(hcount_, 0, N * sizeof(unsigned)));
     in_u8_ = static_cast<uint8_t*>(alloc(N * IN_BYTES));
     o_ypr_ = static_cast<float*>(alloc(N * 3 * sizeof(float)));
     o_amax_ = static_cast<int32_t*>(alloc(N * 3 * sizeof(int32_t)));
@@ -628,9 +634,16 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.ypr = d_ypr;
         a.argmax = d_amax;
         a.n = n;
-        R("heads", "heads", dtype_ == WHENET_F16 ? "whenet_heads_kernel<_Float16>" : "whenet_heads_kernel<float>",
+        // (v.partial is free here: the last squeeze-excite is long done)
+        const bool split = split_heads_ && partial_per_crop_ >= size_t(heads_split()) * N_LOGITS;
+        const std::string hname = std::string(split ? "whenet_heads_split_kernel<" : "whenet_heads_kernel<") +
+                                  (dtype_ == WHENET_F16 ? "_Float16>" : "float>");
+        R("heads", "heads", hname.c_str(),
           double(n) * (HC_ELEMS * es + (N_LOGITS + 6) * 4.0) + double(FEAT) * N_LOGITS * 4.0, 2.0 * n * FEAT * N_LOGITS,
-          [&] { launch_heads(a, dtype_, s); });
+          [&] {
+              if (split) launch_heads_split(a, v.partial, v.hcount, dtype_, s);
+              else launch_heads(a, dtype_, s);
+          });
     }
 }
 
@@ -670,6 +683,7 @@ Engine::View Engine::view(int crop_off) const {
     v.d = static_cast<char*>(d_) + o * D_ELEMS * es;
     v.hc = static_cast<char*>(hc_) + o * HC_ELEMS * es;
     v.partial = partial_ + o * partial_per_crop_;
+    v.hcount = hcount_ + o;
     v.gate = gate_ + o * 1152;
     return v;
 }

@@ -127,6 +127,7 @@ class Engine {
     struct View {          // the activation arena as seen by a sub-batch starting at some crop
         void *x0, *x1, *e, *d, *hc;
         float *partial, *gate;
+        unsigned* hcount;
     };
     View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
@@ -157,6 +158,7 @@ class Engine {
     bool use_graph_ = true;
     int pw_impl_ = 0;
     int repeat_ = 1;
+    bool split_heads_ = true;   // option "split_heads": GAP + Dense over 4 workgroups per crop, the last one decodes
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
     bool fuse_stem_ = false;    // option "fuse_stem": f16, uint8 input: stem + block 1's depthwise as one kernel (stemdw.hip);
                                 // measured: +1 % at 512 crops, equal at 64, 35 us WORSE at batch 1 (7 serial workgroups per crop)
@@ -196,6 +198,7 @@ class Engine {
     size_t arena_bytes_ = 0;
     void *x0_ = nullptr, *x1_ = nullptr, *e_ = nullptr, *d_ = nullptr, *hc_ = nullptr;
     float *partial_ = nullptr, *gate_ = nullptr;
+    unsigned* hcount_ = nullptr;       // per-crop tickets of the split heads kernel (zero between launches)
     uint8_t* in_u8_ = nullptr;
     float* in_f32_ = nullptr;       // normalised float32 input of forward_host_f32 (grown on demand)
     int in_f32_cap_ = 0;

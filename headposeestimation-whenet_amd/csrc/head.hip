@@ -134,7 +134,162 @@ __global__ __launch_bounds__(1024) void whenet_heads_kernel(const T* __restrict_
     }
 }
 
+// The same stage spread over HSPLIT workgroups per crop.  One CU pulls ~50 GB/s from L2 whatever it does, and the
+// Dense kernel is 1.29 MB: a single workgroup per crop needs >= 22 us for it at ANY batch size.  Here workgroup q of a
+// crop pools and contracts channels [320q, 320q + 320) only (322 KB of the kernel), writes its 252 partial logits
+// write-through, and takes a ticket on the crop's counter; the workgroup that draws the last ticket adds the four
+// partial vectors in fixed order (q = 0..3), the bias, and decodes.  The counter is reset by that workgroup (the next
+// launch finds it zero); the order of the additions does not depend on which workgroup finishes last.
+constexpr int HSPLIT = 4, HCH = FEAT / HSPLIT;          // 320 channels per workgroup
+
+__device__ __forceinline__ float ld_l2_f32(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_l2_f32(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bvec,
+                                                                float* __restrict__ logits_out, float* __restrict__ ypr,
+                                                                int32_t* __restrict__ amax, float* __restrict__ part,
+                                                                unsigned* __restrict__ count) {
+    constexpr int NTHR = 512, NW = 8, GP = 6;             // 6 position groups in the pooling
+    __shared__ float s_gap[GP][HCH];
+    __shared__ float s_feat[HCH];
+    __shared__ float s_part[NW][N_LOGITS + 4];
+    __shared__ float s_logit[N_LOGITS + 4];
+    __shared__ unsigned s_ticket;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int wave = tid >> 6, lane = tid & 63;
+
+    // ---- GAP over the 49 positions for this workgroup's channels: lane <-> (4 channels, positions p = grp mod 6)
+    {
+        using V4 = T __attribute__((ext_vector_type(4)));
+        const T* xb = x + size_t(b) * HW * FEAT + q * HCH;
+        const int c4 = tid % (HCH / 4), grp = tid / (HCH / 4);
+        if (grp < GP) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int p = grp + GP * i;
+                if (p < HW) {
+                    const V4 v = *reinterpret_cast<const V4*>(xb + size_t(p) * FEAT + c4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] += float(v[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_gap[grp][c4 * 4 + j] = t[j];
+        }
+    }
+    __syncthreads();
+    if (tid < HCH)
+        s_feat[tid] = (((s_gap[0][tid] + s_gap[1][tid]) + (s_gap[2][tid] + s_gap[3][tid])) + (s_gap[4][tid] + s_gap[5][tid])) *
+                      (1.0f / 49.0f);
+    __syncthreads();
+
+    // ---- Dense partial: 8 waves x 40 channels, lane l owns logits 4l..4l+3 --------------------------------
+    {
+        const int c_lo = wave * (HCH / NW);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < N_LOGITS / 4) {
+            const float* wr = w + size_t(q * HCH + c_lo) * N_LOGITS + lane * 4;
+#pragma unroll 10
+            for (int c = 0; c < HCH / NW; ++c) {
+                const float f = s_feat[c_lo + c];
+                const float4v wv = *reinterpret_cast<const float4v*>(wr + size_t(c) * N_LOGITS);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(f, wv[i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_part[wave][lane * 4 + i] = acc[i];
+        }
+    }
+    __syncthreads();
+    float* mine = part + (size_t(b) * HSPLIT + q) * N_LOGITS;
+    if (tid < N_LOGITS) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) t += s_part[w2][tid];
+        st_l2_f32(mine + tid, t);
+    }
+    // ---- ticket: the partial vector has reached L2 before the counter moves ---------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(count + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == HSPLIT - 1) __hip_atomic_store(count + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ticket = t;
+    }
+    __syncthreads();
+    if (s_ticket != HSPLIT - 1) return;
+
+    // ---- last workgroup of the crop: logits = ((p0 + p1) + p2) + p3 + bias, then the decode -----------------
+    if (tid < N_LOGITS) {
+        const float* pb = part + size_t(b) * HSPLIT * N_LOGITS + tid;
+        const float p0 = ld_l2_f32(pb), p1 = ld_l2_f32(pb + N_LOGITS), p2 = ld_l2_f32(pb + 2 * N_LOGITS),
+                    p3 = ld_l2_f32(pb + 3 * N_LOGITS);
+        const float t = (((p0 + p1) + p2) + p3) + bvec[tid];
+        s_logit[tid] = t;
+        if (logits_out != nullptr) logits_out[size_t(b) * N_LOGITS + tid] = t;
+    }
+    __syncthreads();
+    if (wave >= 3) return;
+    const int lo = (wave == 0) ? 0 : (wave == 1 ? N_YAW : N_YAW + N_PITCH);
+    const int nb = (wave == 0) ? N_YAW : N_PITCH;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = lane; j < nb; j += 64) {
+        const float v = s_logit[lo + j];
+        if (v > mx) { mx = v; mi = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(mx, off, 64);
+        const int oi = __shfl_xor(mi, off, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    float se = 0.0f;
+    float e[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = lane + 64 * i;
+        e[i] = (j < nb) ? expf(s_logit[lo + j] - mx) : 0.0f;
+        se += e[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+    float ex = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = lane + 64 * i;
+        if (j < nb) ex += (e[i] / se) * float(j);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
+    if (lane == 0) {
+        ypr[size_t(b) * 3 + wave] = ex * 3.0f - ((wave == 0) ? 180.0f : 99.0f);
+        if (amax != nullptr) amax[size_t(b) * 3 + wave] = mi;
+    }
+}
+
 }  // namespace
+
+int heads_split() { return HSPLIT; }
+
+void launch_heads_split(const HeadsArgs& a, float* part, unsigned* count, int dtype, hipStream_t stream) {
+    WHENET_REQUIRE(a.x != nullptr && part != nullptr && count != nullptr, WHENET_EINVAL, "heads (split): missing buffers");
+    if (dtype == WHENET_F16)
+        hipLaunchKernelGGL(whenet_heads_split_kernel<half_t>, dim3(HSPLIT, a.n), dim3(512), 0, stream,
+                           static_cast<const half_t*>(a.x), a.w, a.b, a.logits, a.ypr, a.argmax, part, count);
+    else
+        hipLaunchKernelGGL(whenet_heads_split_kernel<float>, dim3(HSPLIT, a.n), dim3(512), 0, stream,
+                           static_cast<const float*>(a.x), a.w, a.b, a.logits, a.ypr, a.argmax, part, count);
+    WHENET_HIP_CHECK(hipGetLastError());
+}
 
 void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream) {
     if (dtype == WHENET_F16 && a.x != nullptr)

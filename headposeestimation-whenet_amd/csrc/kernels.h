@@ -112,6 +112,10 @@ struct HeadsArgs {
     int n;
 };
 void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream);
+// the same stage over heads_split() workgroups per crop; part: [n][heads_split()][252] floats of scratch,
+// count: [n] counters that are zero before the first launch (the kernel leaves them zero)
+void launch_heads_split(const HeadsArgs& a, float* part, unsigned* count, int dtype, hipStream_t stream);
+int heads_split();
 
 // ---- front.hip --------------------------------------------------------------------------
 // expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).
