@@ -351,13 +351,20 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
             }
         }
         lds_barrier();
+        // 16-byte chunks of this stage that exist (narrow layers: N = 16 has 2 per row, not 8): the lanes walk
+        // only those, so a 16-channel project conv stores in one pass instead of four quarter-empty ones
+        int vc = N - (nt0 + t0) * 32;
+        vc = (vc > SW ? SW : vc);
+        vc = (vc > (NT - t0) * 32 ? (NT - t0) * 32 : vc) / CW;
+        const float rvc = __builtin_amdgcn_rcpf(float(vc));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i;
-            const int r = idx >> 3, ch = idx & 7;
+            if (i * 64 >= 32 * vc) break;                           // (wave-uniform)
+            const int r = int((float(idx) + 0.5f) * rvc), ch = idx - r * vc;      // idx / vc, exact (see front.hip)
             const int n = (nt0 + t0) * 32 + ch * CW;
             const int rowg = m0 + r;
-            if (rowg < M && n < N && t0 + ((ch * CW) >> 5) < NT) {
+            if (idx < 32 * vc && rowg < M) {
                 float y[CW];
 #pragma unroll
                 for (int c4 = 0; c4 < CW; c4 += 4) {
