@@ -124,6 +124,10 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
         if (hb.spec.has_expand()) {
             b.fplan = plan_front(dtype_, hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C);
             partial_per_crop_ = std::max(partial_per_crop_, size_t(b.fplan.ntiles()) * b.dw.C);
+            // blocks whose front kernel applies the SE reduce conv write [tiles][chunks][RP] partial vectors: with
+            // narrow chunks that exceeds [tiles][C] (C = 1152, 32-channel chunks: 36 x 48 = 1728 floats per tile)
+            partial_per_crop_ = std::max(partial_per_crop_, size_t(b.fplan.ntiles()) * size_t(b.fplan.chunks) *
+                                                                size_t(se_padded_r(b.se.R)));
         }
         blocks_.push_back(b);
     }

@@ -26,9 +26,11 @@ int main() {
                             {"b13", 5, 1, 7, 192, 1152, 48},  {"b16", 3, 1, 7, 192, 1152, 48}};
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int NMAX = 64;
+    const int NMAX = 256;
     std::string table;
+    const char* only = getenv("TUNE_ONLY");
     for (const Shape& sh : shapes) {
+        if (only && std::string(only) != sh.name) continue;
         using T = half_t;
         const int Ho = ceil_div(sh.H, sh.s);
         const int padt = std::max((Ho - 1) * sh.s + sh.k - sh.H, 0);
@@ -49,30 +51,33 @@ int main() {
         size_t max_tiles = 1;
         for (const FrontPlan& p : cand) max_tiles = std::max(max_tiles, size_t(p.ntiles()));
         float* rp = nullptr;
-        CK(hipMalloc(&rp, size_t(NMAX) * max_tiles * (sh.Cexp + 64) * sizeof(float)));
+        // [tiles][chunks][RP] partial vectors (up to Cexp/32 chunks x (R+3) values) or [tiles][Cexp] channel sums
+        CK(hipMalloc(&rp, size_t(NMAX) * max_tiles * std::max(size_t(sh.Cexp + 64), size_t(sh.Cexp / 32 + 1) * (sh.R + 4)) * sizeof(float)));
         a.rpart = rp;
-        struct Row { FrontPlan p; double score; float t64, t16; };
+        struct Row { FrontPlan p; double score; float t64, t16, t256; };
         std::vector<Row> rows;
         for (size_t i = 0; i < cand.size(); ++i) {
-            Row r{cand[i], scores[i], 0.f, 0.f};
-            for (int n : {64, 16}) {
+            Row r{cand[i], scores[i], 0.f, 0.f, 0.f};
+            if (getenv("TUNE_VERBOSE")) { printf("  cand %zu CC=%d TH=%d NSX=%d EP=%d lds=%zu\n", i, cand[i].CC, cand[i].TH, cand[i].NSX, cand[i].EP, cand[i].lds_bytes); fflush(stdout); }
+            for (int n : {256, 64, 16}) {
                 a.n = n;
                 a.plan = cand[i];
                 a.plan.threads = front_threads(a.plan, n);
                 for (int w = 0; w < 3; ++w) launch_front(a, WHENET_F16, s);
                 CK(hipStreamSynchronize(s));
                 CK(hipEventRecord(e0, s));
-                const int iters = 40;
+                const int iters = (n == 256) ? 12 : 40;
                 for (int w = 0; w < iters; ++w) launch_front(a, WHENET_F16, s);
                 CK(hipEventRecord(e1, s));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                (n == 64 ? r.t64 : r.t16) = ms * 1000.f / iters;
+                (n == 256 ? r.t256 : (n == 64 ? r.t64 : r.t16)) = ms * 1000.f / iters;
             }
             rows.push_back(r);
         }
-        // figure of merit: the in-flight schedule runs 64 crops per launch; small batches run 1-16
-        auto merit = [](const Row& r) { return r.t64 + 1.5f * r.t16; };
+        // figure of merit: the in-flight schedule overlaps several 64-crop launches (throughput regime: the
+        // 256-crop time per 64 crops), one forward at a time runs 64 crops as ~21-crop lanes, small batches run 1-16
+        auto merit = [](const Row& r) { return r.t256 / 4.0f + r.t64 + r.t16; };
         std::sort(rows.begin(), rows.end(), [&](const Row& x, const Row& y) { return merit(x) < merit(y); });
         size_t by_score = 0;
         for (size_t i = 1; i < rows.size(); ++i)
@@ -80,12 +85,19 @@ int main() {
         printf("%s k%d s%d H%d Cexp%d: %zu candidates; a-priori pick is rank %zu (%.1f / %.1f us)\n", sh.name, sh.k, sh.s, sh.H, sh.Cexp,
                rows.size(), by_score + 1, rows[by_score].t64, rows[by_score].t16);
         for (size_t i = 0; i < rows.size() && i < 8; ++i)
-            printf("   #%zu CC=%3d TH=%2d NSX=%d tiles=%dx%d chunks=%2d lds=%5zu EP=%3d score %.3f : n=64 %7.2f us  n=16 %6.2f us\n", i + 1,
+            printf("   #%zu CC=%3d TH=%2d NSX=%d tiles=%dx%d chunks=%2d lds=%5zu EP=%3d score %.3f : n=256 %7.2f us  n=64 %7.2f us  n=16 %6.2f us\n", i + 1,
                    rows[i].p.CC, rows[i].p.TH, rows[i].p.NSX, rows[i].p.tiles_x, rows[i].p.tiles_y, rows[i].p.chunks, rows[i].p.lds_bytes,
-                   rows[i].p.EP, rows[i].score, rows[i].t64, rows[i].t16);
-        char line[160];
-        snprintf(line, sizeof line, "    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s: %.1f us @64, %.1f us @16\n", sh.k, sh.s, sh.H, sh.Cexp,
-                 rows[0].p.CC, rows[0].p.TH, rows[0].p.NSX, rows[0].p.EP - rows[0].p.CC * 2, sh.name, rows[0].t64, rows[0].t16);
+                   rows[i].p.EP, rows[i].score, rows[i].t256, rows[i].t64, rows[i].t16);
+        {
+            const FrontPlan cur = plan_front(WHENET_F16, sh.k, sh.s, sh.H, Ho, sh.Cexp);
+            for (size_t i = 0; i < rows.size(); ++i)
+                if (rows[i].p.CC == cur.CC && rows[i].p.TH == cur.TH && rows[i].p.NSX == cur.NSX && rows[i].p.EP == cur.EP)
+                    printf("   current plan is rank %zu: CC=%d TH=%d NSX=%d EP=%d : n=256 %7.2f  n=64 %7.2f  n=16 %6.2f\n", i + 1, cur.CC,
+                           cur.TH, cur.NSX, cur.EP, rows[i].t256, rows[i].t64, rows[i].t16);
+        }
+        char line[200];
+        snprintf(line, sizeof line, "    {%d, %d, %d, %d, %d, %d, %d, %d},   // %s: %.1f us @256, %.1f us @64, %.1f us @16\n", sh.k, sh.s, sh.H, sh.Cexp,
+                 rows[0].p.CC, rows[0].p.TH, rows[0].p.NSX, rows[0].p.EP - rows[0].p.CC * 2, sh.name, rows[0].t256, rows[0].t64, rows[0].t16);
         table += line;
         for (const void* q : {a.x, a.wep, (const void*)a.be, (const void*)a.wd, (const void*)a.bd, (const void*)a.out,
                               (const void*)a.rpart, (const void*)w1_all})
