@@ -5,7 +5,7 @@ A float64 re-run of the oracle's backbone (oracle/whenet_oracle.py primitives) w
 round-to-binary16 at exactly the places where the HIP f16 path rounds:
   W     BN-folded 1x1-conv weights (the MFMA operands; depthwise taps, biases, SE and the Dense heads stay f32)
   stem  stem output          E   expanded tensor      D   depthwise output
-  G     SE gate, and the gated product D*g fed to the project MFMA
+  Gg    SE gate (stored in T since round 2)        Gp  the gated product D*g fed to the project MFMA
   X     block outputs (the residual stream)            H   head-conv output
 and prints max / mean |angle - f64| over the crops for a few combinations -- among them the
 "f32 residual trunk" (everything but X rounded).  Usage: python tests/f16_error_study.py [ncrops]
@@ -52,8 +52,8 @@ def backbone(x, w, on):
         sq = x.mean(axis=(1, 2), keepdims=True)       # (the kernels sum the f32 values before rounding D)
         x = q("D", x)
         r = O.swish(sq @ w[f"{p}/se_reduce/kernel"][0, 0].astype(np.float64) + w[f"{p}/se_reduce/bias"])
-        g = q("G", O.sigmoid(r @ w[f"{p}/se_expand/kernel"][0, 0].astype(np.float64) + w[f"{p}/se_expand/bias"]))
-        x = q("G", x * g)
+        g = q("Gg", O.sigmoid(r @ w[f"{p}/se_expand/kernel"][0, 0].astype(np.float64) + w[f"{p}/se_expand/bias"]))
+        x = q("Gp", x * g)
         k, b = folded(w, f"{p}/project/kernel", f"{p}/project_bn", "W" in on)
         x = O.conv2d(x, k, 1) + b
         if blk.identity_skip:
@@ -76,13 +76,14 @@ def main():
     w = W.synthetic(1234)
     u8 = np.concatenate([synth.scene_crops(n // 2, seed=5), synth.noise_crops(n - n // 2, seed=6)])
     ref = angles(u8, w, set())
-    ALL = {"W", "stem", "E", "D", "G", "X", "H"}
+    ALL = {"W", "stem", "E", "D", "Gg", "Gp", "X", "H"}
     rows = [("everything the HIP f16 path rounds", ALL),
             ("f32 residual trunk (X kept f32)", ALL - {"X"}),
-            ("f32 residual trunk + f32 gate", ALL - {"X", "G"}),
+            ("f32 residual trunk + f32 gate and product", ALL - {"X", "Gg", "Gp"}),
+            ("gate kept f32, product rounded (round 1)", ALL - {"Gg"}),
             ("only the residual stream X", {"X"}),
             ("only weights W", {"W"}),
-            ("only E", {"E"}), ("only D", {"D"}), ("only gate / gated product", {"G"}),
+            ("only E", {"E"}), ("only D", {"D"}), ("only gate + gated product", {"Gg", "Gp"}), ("only the gate", {"Gg"}),
             ("only stem + head", {"stem", "H"}),
             ("all activations, f32 weights", ALL - {"W"})]
     print(f"{n} crops, synthetic weights seed 1234; |angle - f64 oracle| in degrees")
