@@ -82,6 +82,24 @@ def test_no_cpu_fallback(weights):
     assert e.value.code == _lib.ENODEV
 
 
+def test_yolo_dropin_has_no_cpu_fallback():
+    """whenet_hip.yolo.yolo_eval keeps the reference's signature (yolo_v3/model.py:193-199) and, without a GPU,
+    fails loudly instead of computing on the host."""
+    import inspect
+    import torch
+    from whenet_hip import synth, yolo
+    sig = inspect.signature(yolo.yolo_eval)
+    assert list(sig.parameters)[:7] == ["yolo_outputs", "anchors", "num_classes", "image_shape", "max_boxes",
+                                        "score_threshold", "iou_threshold"]
+    assert (sig.parameters["max_boxes"].default, sig.parameters["score_threshold"].default,
+            sig.parameters["iou_threshold"].default) == (20, .6, .5)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.WhenetError) as e:
+        yolo.yolo_eval(synth.yolo_maps(1), synth.YOLO_ANCHORS, 1, (720, 1280))
+    assert e.value.code == _lib.ENODEV
+
+
 def test_dropin_module_surface():
     import whenet
     assert hasattr(whenet, "WHENet")
