@@ -274,10 +274,6 @@ int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int iters, whenet
     });
 }
 
-int whenet_op_stem_dw(whenet_t* h, const uint8_t* crops, int n, float* dw_out, float* sums) {
-    return guarded(h, [&](whenet::Engine& e) { e.op_stem_dw(crops, n, dw_out, sums); });
-}
-
 int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* out) {
     return guarded(h, [&](whenet::Engine& e) { e.op_stem(crops, n, out); });
 }
@@ -289,13 +285,6 @@ int whenet_op_block(whenet_t* h, int index, const float* in, int n, float* expan
 
 int whenet_op_head(whenet_t* h, const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax) {
     return guarded(h, [&](whenet::Engine& e) { e.op_head(in, n, feat, logits, ypr, argmax); });
-}
-
-int whenet_op_trunk(whenet_t* h, const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
-                   int32_t* argmax, uint64_t* timing) {
-    return guarded(h, [&](whenet::Engine& e) {
-        e.op_trunk(in, n, nblk, x_out, feat, logits, ypr, argmax, reinterpret_cast<unsigned long long*>(timing));
-    });
 }
 
 int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax) {

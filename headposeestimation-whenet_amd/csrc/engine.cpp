@@ -128,25 +128,20 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
             // narrow chunks that exceeds [tiles][C] (C = 1152, 32-channel chunks: 36 x 48 = 1728 floats per tile)
             partial_per_crop_ = std::max(partial_per_crop_, size_t(b.fplan.ntiles()) * size_t(b.fplan.chunks) *
                                                                 size_t(se_padded_r(b.se.R)));
+            if (dtype_ == WHENET_F16) {
+                // f16: the same stage with the depthwise taps on the matrix cores (front2.hip) where that kernel is the
+                // faster one; its Toeplitz image of the depthwise kernel is built once here
+                b.f2plan = plan_front2(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C);
+                b.f2_preferred = front2_preferred(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.dw.C);
+                b.dw.wt = upload(pack_dw_toeplitz(hb.dw.w, hb.spec.k, hb.spec.s, hb.dw.C, b.f2plan.xs));
+                partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f2plan.ntiles()) * b.dw.C);
+                partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f2plan.ntiles()) * size_t(b.f2plan.chunks) *
+                                                                    size_t(se_padded_r(b.se.R)));
+            }
         }
         blocks_.push_back(b);
     }
     head_ = upload_pw(m.head);
-    for (int i = 0; i < 10; ++i) {
-        const DevBlock& b = blocks_[size_t(6 + i)];
-        TrunkBlock& t = trunk_host_[i];
-        t = TrunkBlock{};
-        t.we = b.expand.wp;  t.be = b.expand.bias;
-        t.wd = b.dw.w;       t.bd = b.dw.bias;
-        t.w1t = b.se.w1t;    t.b1 = b.se.b1;   t.w2c = b.se.w2c;   t.b2 = b.se.b2;
-        t.wp = b.project.wp; t.bp = b.project.bias;
-        t.kse = b.expand.KS; t.nte = b.expand.NTILES; t.ksp = b.project.KS; t.ntp = b.project.NTILES;
-        t.k = b.spec.k; t.s = b.spec.s; t.cin = b.spec.cin; t.cexp = b.spec.cexp(); t.cout = b.spec.cout;
-        t.h_in = b.spec.h_in; t.h_out = b.spec.h_out; t.pad = b.spec.pad_before(); t.r = b.se.R;
-        t.rp = se_padded_r(b.se.R);
-        t.has_skip = b.spec.has_skip() ? 1 : 0;
-    }
-    trunk_c_ = (dtype_ == WHENET_F16) ? 4 : 8;
     d_dense_w_ = upload(m.dense_w);
     d_dense_b_ = upload(m.dense_b);
     WHENET_HIP_CHECK(hipDeviceSynchronize());
@@ -178,9 +173,6 @@ Engine::~Engine() {
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
-    if (d_trunk_blocks_) (void)hipFree(d_trunk_blocks_);
-    if (trunk_scratch_) (void)hipFree(trunk_scratch_);
-    if (trunk_counters_) (void)hipFree(trunk_counters_);
     for (hipStream_t st : lane_streams_) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (hipEvent_t ev : join_ev_) (void)hipEventDestroy(ev);
     if (fork_ev_) (void)hipEventDestroy(fork_ev_);
@@ -201,19 +193,12 @@ void Engine::set_option(const std::string& key, long value) {
         fuse_front_ = value != 0;
         sync();
         drop_graphs();
-    } else if (key == "trunk") {
-        trunk_ = value != 0;
+    } else if (key == "front_impl") {
+        WHENET_REQUIRE(value >= 0 && value <= 2, WHENET_EINVAL,
+                       "front_impl must be 0 (front.hip everywhere), 1 (per layer, default) or 2 (front2.hip everywhere, f16)");
+        front_impl_ = int(value);
         sync();
         drop_graphs();
-    } else if (key == "trunk_timing_block") {
-        WHENET_REQUIRE(value >= 0 && value < 10, WHENET_EINVAL, "trunk_timing_block must be 0..9");
-        trunk_timing_block_ = int(value);
-    } else if (key == "trunk_c") {
-        WHENET_REQUIRE(value >= 1 && value <= 16, WHENET_EINVAL, "trunk_c must be 1..16");
-        sync();
-        drop_graphs();
-        trunk_c_ = int(value);
-        trunk_ready_ = false;
     } else if (key == "lanes") {
         WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "lanes must be 1..8");
         lanes_ = int(value);
@@ -221,10 +206,6 @@ void Engine::set_option(const std::string& key, long value) {
         drop_graphs();
     } else if (key == "split_heads") {
         split_heads_ = value != 0;
-        sync();
-        drop_graphs();
-    } else if (key == "fuse_stem") {
-        fuse_stem_ = value != 0;
         sync();
         drop_graphs();
     } else if (key == "lane_graphs") {
@@ -259,16 +240,12 @@ void Engine::get_info(whenet_info_t* out) const {
         // stem + per block {expand, dw | front} {se} project + head conv + heads
         int k = 1 + 2;
         for (const DevBlock& b : blocks_) {
-            const int idx = b.spec.index;
-            if (trunk_ && idx >= 7) continue;
             const bool has_expand = b.spec.expand != 1;
             const bool front = fuse_front_ && has_expand;
             k += front ? 1 : (has_expand ? 2 : 1);
             (void)front;
             k += 2;
         }
-        if (trunk_) k = k - 2 + 1;
-        if (fuse_stem_ && dtype_ == WHENET_F16 && pw_impl_ == 0) k -= 1;     // option: stem + block 1's depthwise as one launch
         out->n_kernels_per_forward = k;
     }
     out->macs_per_crop = 384857312;
@@ -369,7 +346,7 @@ struct Rec {
 }  // namespace
 
 void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                           LaunchRecorder* rec, bool dw_done) {
+                           LaunchRecorder* rec) {
     Rec R{rec, s, repeat_};
     const BlockSpec& sp = b.spec;
     const std::string p = "b" + std::to_string(sp.index);
@@ -377,10 +354,41 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const int hw_in = sp.h_in * sp.h_in, hw_out = sp.h_out * sp.h_out;
     const int cexp = sp.cexp();
     const void* dw_in = in;
-    int se_ntiles = dw_done ? stem_dw_bands() : b.dw.plan.ntiles();     // (dw_done: stemdw.hip wrote v.d and its band sums)
+    int se_ntiles = b.dw.plan.ntiles();
     const bool fused = fuse_front_ && sp.has_expand() && pw_impl_ == 0;
     bool se_in_front = false;
-    if (fused) {
+    int se_chunks = b.fplan.chunks;
+    const bool use_f2 = fused && dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
+    if (use_f2) {
+        Front2Args a{};
+        a.x = in;
+        a.wep = b.expand.wp;
+        a.be = b.expand.bias;
+        a.wdt = b.dw.wt;
+        a.bd = b.dw.bias;
+        a.out = v.d;
+        a.rpart = v.partial;
+        se_in_front = b.se.C >= 480;         // blocks 7-16: the SE reduce conv moves into the front kernel
+        a.w1t = se_in_front ? b.se.w1t : nullptr;
+        a.R = b.se.R;
+        a.k = sp.k;
+        a.s = sp.s;
+        a.H = sp.h_in;
+        a.Ho = sp.h_out;
+        a.Cin = sp.cin;
+        a.Cexp = cexp;
+        a.pad = sp.pad_before();
+        a.KSe = b.expand.KS;
+        a.NTe = b.expand.NTILES;
+        a.n = n;
+        a.plan = b.f2plan;
+        a.plan.threads = front2_threads(b.f2plan, n);
+        se_ntiles = b.f2plan.ntiles();
+        se_chunks = b.f2plan.chunks;
+        R(p + "/front", "front", kernel_name_front2(sp.k, sp.s, a.KSe, a.plan.threads, a.plan.xs).c_str(),
+          double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
+          2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front2(a, s); });
+    } else if (fused) {
         FrontArgs a{};
         a.x = in;
         a.wep = b.expand.wp;
@@ -426,7 +434,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
         dw_in = v.e;
     }
-    if (!fused && !dw_done) {
+    if (!fused) {
         DwArgs a{};
         a.in = dw_in;
         a.out = v.d;
@@ -449,7 +457,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         // (tiles x chunks) partial vectors of every crop): finish the SEBlock
         SeExciteArgs a{};
         a.rpart = v.partial;
-        a.np = se_ntiles * b.fplan.chunks;
+        a.np = se_ntiles * se_chunks;
         a.inv_hw = 1.0f / float(hw_out);
         a.b1 = b.se.b1;
         a.w2c = b.se.w2c;
@@ -501,116 +509,21 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     }
 }
 
-// ---- the trunk launch (trunk.hip) ----------------------------------------------------------------
-void Engine::ensure_trunk() {
-    if (trunk_ready_) return;
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    TrunkBlock blk[10];
-    std::memcpy(blk, trunk_host_, sizeof(blk));
-    trunk_plan_ = plan_trunk(blk, 10, dtype_, trunk_c_, head_.NTILES, head_.K);
-    std::memcpy(trunk_host_, blk, sizeof(blk));
-    if (d_trunk_blocks_ == nullptr) WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_trunk_blocks_), sizeof(blk)));
-    WHENET_HIP_CHECK(hipMemcpy(d_trunk_blocks_, blk, sizeof(blk), hipMemcpyHostToDevice));
-    if (trunk_scratch_) (void)hipFree(trunk_scratch_);
-    if (trunk_counters_) (void)hipFree(trunk_counters_);
-    trunk_scratch_ = nullptr;
-    trunk_counters_ = nullptr;
-    trunk_clusters_ = std::max(1, num_cus_ / trunk_c_);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&trunk_scratch_), size_t(trunk_clusters_) * trunk_plan_.scratch_stride);
-    if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("trunk scratch: ") + hipGetErrorString(e));
-    WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&trunk_counters_), size_t(trunk_clusters_) * 16 * sizeof(unsigned)));
-    WHENET_HIP_CHECK(hipMemset(trunk_counters_, 0, size_t(trunk_clusters_) * 16 * sizeof(unsigned)));
-    trunk_ready_ = true;
-}
-
-TrunkArgs Engine::trunk_args(const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr, int32_t* d_amax,
-                             float* dump_x) {
-    WHENET_REQUIRE(trunk_ready_, WHENET_EINVAL, "trunk: not prepared");
-    TrunkArgs a{};
-    a.blk = d_trunk_blocks_;
-    a.nblk = nblk;
-    a.n = n;
-    a.C = trunk_c_;
-    a.nclusters = std::min(n, trunk_clusters_);
-    a.x_in = x_in;
-    a.x_in_stride = 196 * 80;
-    a.lane_stride = X_ELEMS;
-    a.nlanes = 1;
-    a.lane_start[0] = 0;
-    a.timing_block = trunk_timing_block_;
-    a.scratch = trunk_scratch_;
-    a.scratch_stride = trunk_plan_.scratch_stride;
-    a.xmax = trunk_plan_.xmax;  a.dmax = trunk_plan_.dmax;  a.pmax = trunk_plan_.pmax;
-    a.off_d = trunk_plan_.off_d;  a.off_p = trunk_plan_.off_p;  a.off_r = trunk_plan_.off_r;  a.off_l = trunk_plan_.off_l;
-    a.counters = trunk_counters_;
-    a.fixed_off = trunk_plan_.fixed_off;
-    a.own_cap = trunk_plan_.own_cap;
-    a.wh = head_.wp;  a.bh = head_.bias;  a.ksh = head_.KS;  a.nth = head_.NTILES;
-    a.wdense = d_dense_w_;  a.bdense = d_dense_b_;
-    a.feat = feat;  a.logits = d_logits;  a.ypr = d_ypr;  a.argmax = d_amax;  a.dump_x = dump_x;
-    return a;
-}
-
-void Engine::enqueue_trunk(const void* x_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
-                           LaunchRecorder* rec, int lanes) {
-    Rec R{rec, s, 1};
-    const double es = double(esz());
-    TrunkArgs a = trunk_args(x_in, n, 10, nullptr, d_logits, d_ypr, d_amax, nullptr);
-    a.nlanes = lanes;
-    for (int i = 0, off = 0; i < lanes; ++i) {      // the sub-batch split of enqueue_lanes
-        a.lane_start[i] = off;
-        off += n / lanes + (i < n % lanes ? 1 : 0);
-    }
-    trunk_used_ = true;
-    // per crop: blocks 7-16 + head + heads = 99.6 M MACs; reads 15,680 elements in, ~1 KB out; the 3.3 M weights
-    // are read once per cluster through L2
-    R("trunk", "trunk", kernel_name_trunk(dtype_).c_str(),
-      double(n) * (196.0 * 80.0 * es + 1020.0) + 3302000.0 * es, 2.0 * n * 99.6e6,
-      [&] { launch_trunk(a, trunk_plan_.lds_bytes, dtype_, s); });
-}
-
-// A cluster whose members did not all arrive within the poll bound sets its error word (trunk.hip): the
-// results of that forward are garbage, and the caller must hear about it.
-void Engine::check_trunk_error() {
-    if (!trunk_used_ || trunk_counters_ == nullptr) return;
-    trunk_used_ = false;
-    std::vector<unsigned> host(size_t(trunk_clusters_) * 16);
-    WHENET_HIP_CHECK(hipMemcpy(host.data(), trunk_counters_, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-    for (int c = 0; c < trunk_clusters_; ++c)
-        if (host[size_t(c) * 16 + 1] != 0)
-            throw Error(WHENET_EHIP, "trunk kernel: cluster " + std::to_string(c) +
-                                         " timed out waiting for its members (workgroups not co-resident?)");
-}
-
 void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
-                             hipStream_t s, LaunchRecorder* rec, const float* d_in_f32, bool front_only) {
+                             hipStream_t s, LaunchRecorder* rec, const float* d_in_f32) {
     Rec R{rec, s, repeat_};
     const double es = double(esz());
-    // f16, uint8 input: the stem and block 1's depthwise conv are one row-streaming launch (stemdw.hip); the stem
-    // output never reaches HBM, block 1 starts at its squeeze-excite
-    const bool stem_dw = fuse_stem_ && dtype_ == WHENET_F16 && d_in_f32 == nullptr && pw_impl_ == 0;
-    if (stem_dw) {
-        const DevBlock& b1 = blocks_[0];
-        StemDwArgs a{d_in, v.d, v.partial, d_stem_w_, d_stem_b_, d_lut_, b1.dw.w, b1.dw.bias, n};
-        R("stem+b1/dw", "stem", kernel_name_stem_dw(), double(n) * (IN_BYTES + X_ELEMS * es),
-          2.0 * n * (10838016.0 + 9.0 * X_ELEMS), [&] { launch_stem_dw(a, s); });
-    } else {
+    {
         StemArgs a{d_in, v.x0, d_stem_w_, d_stem_b_, d_lut_, n};
         a.in_f32 = d_in_f32;
         R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
           [&] { launch_stem(a, dtype_, s); });
     }
     void* cur = v.x0;
-    const size_t nlayer = trunk_ ? 6 : blocks_.size();
-    for (size_t i = 0; i < nlayer; ++i) {
+    for (size_t i = 0; i < blocks_.size(); ++i) {
         void* nxt = (cur == v.x0) ? v.x1 : v.x0;
-        enqueue_block(blocks_[i], v, cur, nxt, n, s, rec, stem_dw && i == 0);
+        enqueue_block(blocks_[i], v, cur, nxt, n, s, rec);
         cur = nxt;
-    }
-    if (trunk_) {
-        // (with sub-batch lanes the caller joins the lanes first and launches ONE trunk over the whole batch)
-        if (!front_only) enqueue_trunk(cur, n, d_ypr, d_amax, d_logits, s, rec, 1);
-        return;
     }
     {
         PwArgs a{};
@@ -710,18 +623,15 @@ void Engine::enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_
         const int cnt = n / lanes + (i < n % lanes ? 1 : 0);
         hipStream_t st = (i == 0) ? s : lane_stream(i - 1);
         if (i > 0) WHENET_HIP_CHECK(hipStreamWaitEvent(st, fork_ev_, 0));
-        // with the trunk kernel the lanes cover stem + blocks 1..6 only and join before ONE trunk launch over
-        // the whole batch (its clusters share the engine's scratch, and it fills the chip by itself)
         enqueue_forward(view(off), d_in + size_t(off) * IN_BYTES, cnt, d_ypr + size_t(off) * 3,
                         d_amax ? d_amax + size_t(off) * 3 : nullptr, d_logits ? d_logits + size_t(off) * N_LOGITS : nullptr,
-                        st, nullptr, nullptr, trunk_);
+                        st, nullptr);
         if (i > 0) {
             WHENET_HIP_CHECK(hipEventRecord(join_ev_[size_t(i - 1)], st));
             WHENET_HIP_CHECK(hipStreamWaitEvent(s, join_ev_[size_t(i - 1)], 0));
         }
         off += cnt;
     }
-    if (trunk_) enqueue_trunk(block6_out(view(0)), n, d_ypr, d_amax, d_logits, s, nullptr, lanes);
 }
 
 // Capture fn's launches on stream s into an executable graph (cached under key) and return it.
@@ -730,7 +640,8 @@ hipGraphExec_t Engine::cached_graph(const GraphKey& key, hipStream_t s, F&& fn) 
     auto it = graphs_.find(key);
     if (it != graphs_.end()) return it->second;
     if (graphs_.size() >= size_t(MAX_GRAPHS)) {
-        sync_streams(s);
+        sync_streams(s);                 // (s may be a lane stream: the main stream's graphs are in flight too)
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
         drop_graphs();
     }
     hipGraph_t graph = nullptr;
@@ -752,7 +663,6 @@ hipGraphExec_t Engine::cached_graph(const GraphKey& key, hipStream_t s, F&& fn) 
 }
 
 void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
-    if (trunk_) ensure_trunk();          // allocations / uploads must not land inside a stream capture
     if (!use_graph_) {
         enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
         return;
@@ -760,7 +670,7 @@ void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_am
     int lanes = lanes_;
     while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
     if (lanes > 1) (void)lane_stream(lanes - 2);        // the lane streams exist before any capture starts
-    if (lane_graphs_ && lanes > 1 && !trunk_) {
+    if (lane_graphs_ && lanes > 1) {
         // One graph PER LANE, each launched on its own stream: the chains then run as independent queues.
         // (Branches of a single graph cost ~5 us per edge on this runtime, which eats the overlap.)
         WHENET_HIP_CHECK(hipEventRecord(fork_ev_, s));
@@ -814,7 +724,6 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
     if (logits)
         WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    check_trunk_error();
 }
 
 // Model.predict on the NORMALISED float32 image (whenet.py:27) + decode: the path for real-valued
@@ -834,7 +743,6 @@ void Engine::forward_host_f32(const float* x, int n, float* ypr, int32_t* argmax
         if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("float input buffer: ") + hipGetErrorString(e));
         in_f32_cap_ = n;
     }
-    if (trunk_) ensure_trunk();
     WHENET_HIP_CHECK(hipMemcpyAsync(in_f32_, x, N * IN_BYTES * sizeof(float), hipMemcpyHostToDevice, stream_));
     enqueue_forward(view(0), nullptr, n, o_ypr_, o_amax_, o_logits_, stream_, nullptr, in_f32_);
     WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -842,7 +750,6 @@ void Engine::forward_host_f32(const float* x, int n, float* ypr, int32_t* argmax
     if (logits)
         WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    check_trunk_error();
 }
 
 void Engine::sync_streams(hipStream_t s) {
@@ -855,7 +762,6 @@ void Engine::sync() {
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
     if (copy_stream_) WHENET_HIP_CHECK(hipStreamSynchronize(copy_stream_));
     for (hipStream_t st : lane_streams_) WHENET_HIP_CHECK(hipStreamSynchronize(st));
-    check_trunk_error();
 }
 
 void Engine::ensure_slot(Slot& s, int n) {
@@ -922,7 +828,6 @@ void Engine::collect(int ticket, float* ypr, int32_t* argmax, float* logits) {
         if (s.busy && s.ticket == ticket) slot = &s;
     WHENET_REQUIRE(slot != nullptr, WHENET_EINVAL, "unknown or already collected ticket " + std::to_string(ticket));
     WHENET_HIP_CHECK(hipEventSynchronize(slot->done));
-    check_trunk_error();
     const size_t N = size_t(slot->n);
     if (ypr) std::memcpy(ypr, slot->h_ypr, N * 3 * sizeof(float));
     if (argmax) std::memcpy(argmax, slot->h_amax, N * 3 * sizeof(int32_t));
@@ -1129,8 +1034,7 @@ int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat
     DeviceGuard guard(device_);
     WHENET_REQUIRE(d_crops != nullptr && iters >= 1, WHENET_EINVAL, "profile: bad arguments");
     ensure_capacity(n);
-    if (trunk_) ensure_trunk();
-    int lanes = trunk_ ? 1 : lanes_;       // (the trunk launch covers the whole batch: one chain)
+    int lanes = lanes_;
     while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
     std::vector<LaunchRecorder> recs;
     recs.resize(size_t(lanes));
@@ -1216,26 +1120,6 @@ void Engine::op_stem(const uint8_t* crops, int n, float* out) {
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
-// f16 only: the fused stem + block-1 depthwise launch on host crops; dw_out [n,112,112,32] as f32, sums [n][bands][32]
-void Engine::op_stem_dw(const uint8_t* crops, int n, float* dw_out, float* sums) {
-    DeviceGuard guard(device_);
-    WHENET_REQUIRE(crops && dw_out, WHENET_EINVAL, "op_stem_dw: NULL argument");
-    WHENET_REQUIRE(dtype_ == WHENET_F16, WHENET_EINVAL, "op_stem_dw: the fused launch exists for the f16 configuration only");
-    ensure_capacity(n);
-    TempBufs tmp;
-    const size_t N = size_t(n);
-    float* d_out = static_cast<float*>(tmp.get(N * X_ELEMS * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
-    StemDwArgs a{in_u8_, d_, partial_, d_stem_w_, d_stem_b_, d_lut_, blocks_[0].dw.w, blocks_[0].dw.bias, n};
-    launch_stem_dw(a, stream_);
-    launch_act_to_f32(d_, d_out, N * X_ELEMS, dtype_, stream_);
-    WHENET_HIP_CHECK(hipMemcpyAsync(dw_out, d_out, N * X_ELEMS * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (sums)
-        WHENET_HIP_CHECK(hipMemcpyAsync(sums, partial_, N * size_t(stem_dw_bands()) * 32 * sizeof(float),
-                                        hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
 void Engine::op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out) {
     DeviceGuard guard(device_);
     WHENET_REQUIRE(index >= 1 && index <= int(blocks_.size()), WHENET_EINVAL, "op_block: index must be 1..16");
@@ -1308,47 +1192,6 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
     if (ypr) WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_trunk(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr,
-                      int32_t* argmax, unsigned long long* timing) {
-    DeviceGuard guard(device_);
-    WHENET_REQUIRE(in != nullptr && nblk >= 1 && nblk <= 10, WHENET_EINVAL, "op_trunk: bad arguments");
-    ensure_capacity(n);
-    const size_t N = size_t(n);
-    const size_t in_elems = 196 * 80;
-    const BlockSpec& last = blocks_[size_t(6 + nblk - 1)].spec;
-    const size_t out_elems = N * last.h_out * last.h_out * last.cout;
-    TempBufs tmp;
-    float* d_f32 = static_cast<float*>(tmp.get(std::max(N * in_elems, out_elems) * sizeof(float)));
-    float* d_feat = static_cast<float*>(tmp.get(N * FEAT * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, N * in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
-    launch_f32_to_act(d_f32, x0_, N * in_elems, dtype_, stream_);      // [n][14][14][80] as block 6 leaves it
-    const bool dump = x_out != nullptr;
-    WHENET_REQUIRE(dump || nblk == 10, WHENET_EINVAL, "op_trunk: the head needs all 10 blocks");
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    ensure_trunk();
-    TrunkArgs a = trunk_args(x0_, n, nblk, d_feat, o_logits_, o_ypr_, o_amax_, dump ? d_f32 : nullptr);
-    trunk_used_ = true;
-    unsigned long long* d_timing = nullptr;
-    if (timing) {
-        d_timing = static_cast<unsigned long long*>(tmp.get(192 * sizeof(unsigned long long)));
-        WHENET_HIP_CHECK(hipMemsetAsync(d_timing, 0, 192 * sizeof(unsigned long long), stream_));
-        launch_trunk(a, trunk_plan_.lds_bytes, dtype_, stream_);     // warm (weights into L2), then the timed one
-        a.timing = d_timing;
-    }
-    launch_trunk(a, trunk_plan_.lds_bytes, dtype_, stream_);
-    if (timing) WHENET_HIP_CHECK(hipMemcpyAsync(timing, d_timing, 192 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream_));
-    if (dump) {
-        WHENET_HIP_CHECK(hipMemcpyAsync(x_out, d_f32, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    } else {
-        if (feat) WHENET_HIP_CHECK(hipMemcpyAsync(feat, d_feat, N * FEAT * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        if (logits) WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        if (ypr) WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    }
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    check_trunk_error();
 }
 
 void Engine::op_decode(const float* logits, int n, float* ypr, int32_t* argmax) {

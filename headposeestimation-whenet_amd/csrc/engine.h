@@ -1,5 +1,5 @@
 // The per-GPU inference engine behind the C ABI: device weights, activation arena, launch
-// schedule of the 51 kernels of one forward, hipGraph cache, per-launch profiling, and the
+// schedule of the kernels of one forward, hipGraph cache, per-launch profiling, and the
 // pinned-buffer submit/collect pipeline.  One engine = one device + one stream; not thread-safe.
 #pragma once
 
@@ -25,6 +25,7 @@ struct DevDw {
     int k = 0, C = 0;
     float* w = nullptr;
     float* bias = nullptr;
+    half_t* wt = nullptr;      // f16: Toeplitz operand image of the kernel for front2.hip (pack_dw_toeplitz)
     DwPlan plan;
 };
 struct DevSe {
@@ -37,6 +38,8 @@ struct DevBlock {
     DevPw expand;
     DevDw dw;
     FrontPlan fplan;       // fused expand+depthwise tiling (blocks with an expand conv)
+    Front2Plan f2plan;     // f16: the same stage with the taps on the matrix cores (front2.hip)
+    bool f2_preferred = false;
     DevSe se;
     DevPw project;
 };
@@ -85,12 +88,9 @@ class Engine {
                   int num_anchors, int num_classes, float image_h, float image_w, float score_threshold,
                   float iou_threshold, int max_boxes, float* boxes, float* scores, int32_t* classes, int32_t* index,
                   float* all_boxes, float* all_scores);
-    void op_stem_dw(const uint8_t* crops, int n, float* dw_out, float* sums);
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
-    void op_trunk(const float* in, int n, int nblk, float* x_out, float* feat, float* logits, float* ypr, int32_t* argmax,
-                  unsigned long long* timing);
 
     void* dev_alloc(size_t nbytes);
     void dev_free(void* p);
@@ -132,16 +132,9 @@ class Engine {
     View view(int crop_off) const;
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
     void enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
-                         hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr, bool front_only = false);
-    const void* block6_out(const View& v) const { return v.x0; }      // 6 blocks from x0: x0 -> x1 -> ... -> x0
+                         hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr);
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                       LaunchRecorder* rec, bool dw_done = false);
-    TrunkArgs trunk_args(const void* x_in, int n, int nblk, float* feat, float* d_logits, float* d_ypr, int32_t* d_amax,
-                         float* dump_x);
-    void ensure_trunk();
-    void enqueue_trunk(const void* x_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s,
-                       LaunchRecorder* rec, int lanes);
-    void check_trunk_error();
+                       LaunchRecorder* rec);
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
@@ -159,22 +152,9 @@ class Engine {
     int pw_impl_ = 0;
     int repeat_ = 1;
     bool split_heads_ = true;   // option "split_heads": GAP + Dense over 4 workgroups per crop, the last one decodes
-    bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip)
-    bool fuse_stem_ = false;    // option "fuse_stem": f16, uint8 input: stem + block 1's depthwise as one kernel (stemdw.hip);
-                                // measured: +1 % at 512 crops, equal at 64, 35 us WORSE at batch 1 (7 serial workgroups per crop)
-    bool trunk_ = false;        // option "trunk": blocks 7..16 + head + heads as ONE persistent launch, a cluster of
-                                // trunk_c_ workgroups per crop (trunk.hip).  Correct and tested; measured slower than
-                                // one launch per layer at every batch size, so it is off by default
-    int trunk_c_ = 4;           // option "trunk_c": workgroups per cluster (fixed per handle: it fixes the summation order)
-    TrunkBlock trunk_host_[10]; // block descriptors of blocks 7..16 (host copy + device table)
-    TrunkBlock* d_trunk_blocks_ = nullptr;
-    TrunkPlan trunk_plan_{};
-    bool trunk_ready_ = false;
-    int trunk_clusters_ = 0;    // clusters the scratch was allocated for (= CUs / trunk_c_)
-    unsigned char* trunk_scratch_ = nullptr;
-    unsigned* trunk_counters_ = nullptr;
-    int trunk_timing_block_ = 3;   // debug option "trunk_timing_block": block (0..9) with detailed phase stamps
-    bool trunk_used_ = false;   // a trunk launch happened since the error words were last checked
+    bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip / front2.hip)
+    int front_impl_ = 1;        // option "front_impl": 0 = front.hip everywhere, 1 = per layer (f16: front2.hip where it is
+                                // the faster kernel), 2 = front2.hip everywhere (f16)
     int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")
     bool lane_graphs_ = false;  // one graph per lane on its own stream instead of one forked graph (option "lane_graphs")
     int min_lane_crops_ = 16;   // do not split below this many crops per chain

@@ -152,22 +152,43 @@ struct FrontArgs {
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);
 
-// ---- stemdw.hip -------------------------------------------------------------------------
-// f16 configuration, uint8 input: stem + block 1's depthwise conv as one row-streaming kernel.
-struct StemDwArgs {
-    const uint8_t* in;     // [n,224,224,3]
-    void* out;             // [n,112,112,32] half: block 1's depthwise output
-    float* partial;        // [n][stem_dw_bands()][32] channel sums of that output per band
-    const float* w;        // stem [27][32]
-    const float* bias;     // stem [32]
-    const float* lut;      // [3][256]
-    const float* wd;       // block 1 depthwise [9][32]
-    const float* bd;       // [32]
-    int n;
+// ---- front2.hip -------------------------------------------------------------------------
+// f16: the same stage with the depthwise taps on the matrix cores (per-channel Toeplitz products,
+// v_mfma_f32_4x4x4_16B_f16) and the expanded tile channel-major in LDS.
+struct Front2Plan {
+    int threads = 256;     // lanes per workgroup (256 | 512)
+    int CC = 32;           // expanded channels per workgroup (multiple of 32, or the whole layer)
+    int TH = 7;            // output rows per tile (multiple of 7)
+    int TXG = 1;           // 4-pixel output groups per tile row
+    int xs = 0;            // tile origin moved this many pixels to the left (0 | 2)
+    int tiles_x = 1, tiles_y = 1, chunks = 1;
+    int EH = 0, EWp = 0;   // LDS tile of the expanded input: rows, pixels per row (multiple of 4)
+    int RP = 0, CP = 0;    // row / channel pitch in bytes
+    int off_stage = 0, off_red = 0, off_sum = 0;
+    size_t lds_bytes = 0;
+    int ntiles() const { return tiles_x * tiles_y; }
 };
-void launch_stem_dw(const StemDwArgs& a, hipStream_t stream);
-int stem_dw_bands();
-const char* kernel_name_stem_dw();
+Front2Plan make_front2_plan(int k, int s, int Ho, int Cexp, int CC, int TH, int TXG, int threads, int xs);
+Front2Plan plan_front2(int k, int s, int H, int Ho, int Cexp);
+std::vector<Front2Plan> plan_front2_candidates(int k, int s, int Ho, int Cexp);
+int front2_threads(const Front2Plan& p, int n);
+std::vector<half_t> pack_dw_toeplitz(const std::vector<float>& w, int k, int s, int C, int xs);
+bool front2_preferred(int k, int s, int H, int Cexp);
+struct Front2Args {
+    const void* x;         // [n,H,H,Cin] half  block input
+    const void* wep;       // packed expand weights (MFMA fragment order, snapshot.h)
+    const float* be;       // [Cexp]
+    const void* wdt;       // pack_dw_toeplitz() image of the depthwise kernel (for plan.xs)
+    const float* bd;       // [Cexp]
+    void* out;             // [n,Ho,Ho,Cexp] half
+    float* rpart;          // as FrontArgs::rpart
+    const float* w1t;      // [R][Cexp] se_reduce kernel, transposed, or NULL
+    int R;
+    int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
+    Front2Plan plan;
+};
+void launch_front2(const Front2Args& a, hipStream_t stream);
+std::string kernel_name_front2(int k, int s, int kse, int threads, int xs);
 
 // ---- yolo.hip ---------------------------------------------------------------------------
 // YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.
@@ -205,57 +226,6 @@ void frame_box_rect(int frame_h, int frame_w, const float bbox[4], int32_t rect[
 void build_crop_plan(const int32_t rect[4], int32_t* plan);
 void launch_crop_resize(const uint8_t* d_frame, int fw, int swap_rb, const int32_t* d_plan, int k, uint8_t* d_out,
                         hipStream_t stream);
-
-// ---- trunk.hip --------------------------------------------------------------------------
-// Blocks 7..16 + head conv + GAP + Dense + decode as ONE persistent launch; a crop is processed by a
-// cluster of C workgroups that split every layer's channels and synchronise only with each other.
-struct TrunkBlock {
-    const void* we;  const float* be;              // expand: packed MFMA image, bias [cexp]
-    const float* wd; const float* bd;              // depthwise [k*k][cexp], bias
-    const float *w1t, *b1, *w2c, *b2;              // squeeze-excite: reduce [R][cexp], excite [cexp][RP] channel-major
-    const void* wp;  const float* bp;              // project: packed MFMA image, bias [cout]
-    int kse, nte, ksp, ntp;                        // k-steps / 32-wide tiles of the two GEMMs
-    int k, s, cin, cexp, cout, h_in, h_out, pad, r, rp, has_skip;
-    int sub_tiles;                                 // 32-channel tiles of the expanded tensor per LDS sub-chunk
-    int dbuf;                                      // 1: two E / taps / strip-sum buffers (expand(s+1) beside taps(s))
-    int vc;                                        // channels per depthwise lane-task (2 | 4)
-    int off_e, e_bytes, off_dww, off_red;          // LDS byte offsets of E / depthwise taps / strip sums (plan_trunk)
-    int wp_lds;                                    // 1: the own k-steps of the project weights are staged in LDS
-};
-struct TrunkPlan {
-    int C;                                         // workgroups per cluster
-    int fixed_off;                                 // LDS offset of the small per-workgroup arrays
-    int own_cap;                                   // largest channel share of a member over all blocks
-    size_t lds_bytes;
-    size_t xmax, dmax, pmax;                       // elements: block in/out, own depthwise output, project partial
-    size_t off_d, off_p, off_r, off_l;             // byte offsets inside a cluster's scratch
-    size_t scratch_stride;                         // bytes of scratch per cluster
-};
-TrunkPlan plan_trunk(TrunkBlock* blk, int nblk, int dtype, int C, int head_nth, int head_cin);
-struct TrunkArgs {
-    const TrunkBlock* blk;   // [nblk] block descriptors in DEVICE memory (built once per handle)
-    int nblk, n, C, nclusters;
-    const void* x_in;        // output of block 6: crop c of lane l at (lane_start[l] * lane_stride +
-    size_t x_in_stride;      //   (c - lane_start[l]) * x_in_stride) elements; x_in_stride = 14*14*80
-    size_t lane_stride;      // elements the arena reserves per crop (the layer-wise front half packs each
-    int nlanes;              //   sub-batch lane contiguously from its first crop's slot)
-    int lane_start[8];
-    unsigned char* scratch;  // [nclusters][scratch_stride]
-    size_t scratch_stride, xmax, dmax, pmax, off_d, off_p, off_r, off_l;
-    unsigned* counters;      // [nclusters][16]: arrival counter, error word (zeroed by the launcher)
-    int fixed_off, own_cap;
-    const void* wh;  const float* bh;  int ksh, nth;   // head conv
-    const float* wdense;  const float* bdense;         // [1280][252], [252]
-    float* feat;             // [n][1280] or nullptr
-    float* logits;           // [n][252] or nullptr
-    float* ypr;              // [n][3]
-    int32_t* argmax;         // [n][3] or nullptr
-    unsigned long long* timing;   // debug: [192] wall-clock stamps of workgroup 0's phases, or nullptr
-    int timing_block;        // detailed stamps (timing[128..]) for this block index
-    float* dump_x;           // test hook: stop after the blocks and write X as f32 [n][HW][C]
-};
-void launch_trunk(const TrunkArgs& a, size_t lds_bytes, int dtype, hipStream_t stream);
-std::string kernel_name_trunk(int dtype);
 
 // ---- convert.hip ------------------------------------------------------------------------
 void launch_empty(hipStream_t stream);   // boundary calibration for whenet_profile()

@@ -54,10 +54,8 @@ _PROTOS = {
                                    C.c_float, C.c_float, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_int), _P, _P]),
     "whenet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
-    "whenet_op_stem_dw": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "whenet_op_head": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
-    "whenet_op_trunk": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "whenet_op_decode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "whenet_block_spec": (C.c_int, [C.c_int, C.POINTER(C.c_int32 * 8)]),
     "whenet_dw_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32 * 12)]),
@@ -342,13 +340,6 @@ class Handle:
         self._check(self._lib.whenet_op_stem(self._h, _ptr(crops), n, _ptr(out)))
         return out
 
-    def op_stem_dw(self, crops: np.ndarray):
-        n = crops.shape[0]
-        dw = np.empty((n, 112, 112, 32), np.float32)
-        sums = np.empty((n, 7, 32), np.float32)
-        self._check(self._lib.whenet_op_stem_dw(self._h, _ptr(crops), n, _ptr(dw), _ptr(sums)))
-        return dw, sums
-
     def op_block(self, index: int, x: np.ndarray):
         from . import spec
         b = spec.blocks()[index - 1]
@@ -372,24 +363,6 @@ class Handle:
         am = np.empty((n, 3), np.int32)
         self._check(self._lib.whenet_op_head(self._h, _ptr(x), n, _ptr(feat), _ptr(lg), _ptr(ypr), _ptr(am)))
         return {"feat": feat, "logits": lg, "ypr": ypr, "argmax": am}
-
-    def op_trunk(self, x: np.ndarray, nblk: int = 10, dump: bool = False):
-        from . import spec
-        x = np.ascontiguousarray(x, np.float32)
-        n = x.shape[0]
-        assert x.shape[1:] == (14, 14, 80)
-        if dump:
-            b = spec.blocks()[6 + nblk - 1]
-            out = np.empty((n, b.h_out, b.h_out, b.cout), np.float32)
-            self._check(self._lib.whenet_op_trunk(self._h, _ptr(x), n, nblk, _ptr(out), None, None, None, None, None))
-            return out
-        feat = np.empty((n, 1280), np.float32)
-        lg = np.empty((n, 252), np.float32)
-        ypr = np.empty((n, 3), np.float32)
-        am = np.empty((n, 3), np.int32)
-        tm = np.zeros(192, np.uint64)
-        self._check(self._lib.whenet_op_trunk(self._h, _ptr(x), n, 10, None, _ptr(feat), _ptr(lg), _ptr(ypr), _ptr(am), _ptr(tm)))
-        return {"feat": feat, "logits": lg, "ypr": ypr, "argmax": am, "timing": tm}
 
     def op_decode(self, logits: np.ndarray):
         lg = np.ascontiguousarray(logits, np.float32)

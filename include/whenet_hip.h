@@ -93,15 +93,10 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
  *          "fuse_front" (0/1, default 1: expand 1x1 + depthwise as ONE kernel per block, the
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
- *          "trunk" (0/1, default 0: 1 = blocks 7..16 + head conv + heads as ONE persistent launch in which a
- *                  cluster of "trunk_c" workgroups (one per CU) processes a crop, splitting every layer's
- *                  channels and synchronising only inside the cluster; measured no faster than one launch
- *                  per layer, kept as an option with its tests),
- *          "trunk_c" (1..16, default 4 for f16 / 8 for f32: workgroups per cluster; fixed per handle
- *                  because it fixes the summation order of the project convs),
- *          "fuse_stem" (0/1, default 0: f16 configuration, uint8 input: stem + block 1's depthwise conv as ONE
- *                  row-streaming launch, the stem output stays in LDS; measured +1 % at 512 crops, equal at 64,
- *                  35 us slower at batch 1, so it is an option),
+ *          "front_impl" (0..2, default 1: which fused kernel an f16 handle uses -- 0 = front.hip (depthwise taps
+ *                  as f32 VALU FMAs) on every block, 2 = front2.hip (taps as Toeplitz products on the matrix
+ *                  cores, f16 tap weights) on every block, 1 = per layer, whichever was measured faster;
+ *                  f32 handles always run front.hip),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "lane_graphs" (0/1, default 0: 1 = one graph per lane launched on its own stream instead of
  *                  one forked graph; measured equal),
@@ -211,9 +206,6 @@ WHENET_API int whenet_profile(whenet_t* h, const uint8_t* d_crops, int n, int it
  * shape.  Any output pointer may be NULL. */
 /* stem: normalise + Conv3x3/s2 + BN + Swish.  out [n,112,112,32] */
 WHENET_API int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* out);
-/* f16 configuration: stem + block 1's depthwise conv as the one launch the forward uses (stemdw.hip):
- * dw_out float [n,112,112,32] (block 1's depthwise output), sums float [n][7][32] per-band channel sums (may be NULL) */
-WHENET_API int whenet_op_stem_dw(whenet_t* h, const uint8_t* crops, int n, float* dw_out, float* sums);
 /* MBConv block `index` (1..16) on input [n,H,W,Cin]:
  *   expand_out [n,H,W,Cexp] (NULL for block 1), dw_out [n,Ho,Wo,Cexp], gate [n,Cexp],
  *   out [n,Ho,Wo,Cout] (after project + BN + skip) */
@@ -223,12 +215,6 @@ WHENET_API int whenet_op_block(whenet_t* h, int index, const float* in, int n,
  *   feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3] */
 WHENET_API int whenet_op_head(whenet_t* h, const float* in, int n,
                    float* feat, float* logits, float* ypr, int32_t* argmax);
-/* the trunk launch alone (blocks 7..16 + head conv + GAP + Dense + decode, one cluster of workgroups
- * per crop) on input [n,14,14,80] = block 6's output.  With x_out != NULL only the first `nblk`
- * (1..10) blocks run and their output [n,Ho,Ho,Cout] is returned; with x_out == NULL
- * (nblk must be 10) the head runs too: feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3]. */
-WHENET_API int whenet_op_trunk(whenet_t* h, const float* in, int n, int nblk, float* x_out,
-                    float* feat, float* logits, float* ypr, int32_t* argmax, uint64_t* timing /* [192] or NULL */);
 /* decode only (whenet.py:28-33) on caller logits [n,252] -> ypr [n,3], argmax [n,3] */
 WHENET_API int whenet_op_decode(whenet_t* h, const float* logits, int n, float* ypr, int32_t* argmax);
 

@@ -142,3 +142,18 @@ def test_oracle_class_surface(weights, golden):
     assert y.shape == p.shape == r.shape == (1,)
     with pytest.raises(ValueError):
         m.get_angle(np.zeros((224, 224, 3), np.uint8))
+
+
+def test_f16_set_fixture_is_the_oracle(weights):
+    """tests/golden/f16_set_expected.npz (the 48-crop accuracy contract of the GPU suite) is what
+    oracle/whenet_oracle.py computes for those seeded crops: re-derived here for a sample of them."""
+    import os
+    from whenet_hip import synth
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set_expected.npz"))
+    crops = np.concatenate([synth.scene_crops(24, seed=5), synth.noise_crops(24, seed=6)])
+    idx = [0, 23, 24, 47]
+    ref = O.forward(crops[idx], weights, np.float64)
+    assert np.abs(np.stack([ref["yaw"], ref["pitch"], ref["roll"]], 1) - fx["angles"][idx]).max() < 1e-9
+    assert np.allclose(ref["logits"], fx["logits"][idx], rtol=1e-6, atol=1e-5)          # (stored as float32)
+    assert np.array_equal(ref["argmax"], fx["argmax"][idx])
+    assert fx["angles"].shape == (48, 3) and fx["logits"].shape == (48, 252)
