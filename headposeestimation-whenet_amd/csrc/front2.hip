@@ -32,6 +32,7 @@
 // HBM bytes per crop: H^2*Cin (x chunks, L2 hits) + Ho^2*Cexp written once.
 #include "device_math.h"
 #include "kernels.h"
+#include "stamps.h"
 
 #include <cstdlib>
 #include <string>
@@ -64,17 +65,33 @@ struct F2Params {
     int R, RPse;
 };
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// Swish of two values with packed f32 arithmetic: v_pk_add_f32 / v_pk_mul_f32 for the three plain steps, the two
+// quarter-rate transcendentals per value (v_exp_f32, v_rcp_f32) unpacked: 3.5 instructions per value instead of 5.5.
+// Same operations in the same order as device_math.h's swish_f<false> (x * rcp(1 + exp2(-x * log2(e)))): same bits.
+__device__ __forceinline__ float2v swish2(float2v x) {
+    const float2v t = x * float2v{-1.4426950408889634f, -1.4426950408889634f};
+    const float2v d = float2v{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + float2v{1.0f, 1.0f};
+    return x * float2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
 // BN + Swish of one expand task (32 pixels x 32 channels; this lane: channel ch, four runs of 4 consecutive pixels)
 // into the tile.  EDGE: the strip hangs over the in-image rows / groups -- those runs are skipped.
 template <bool EDGE>
 __device__ __forceinline__ void expand_store(const float16v& acc, float bias, unsigned char* ep, const int (&eoff)[4],
                                              const int (&drd)[4], const int (&dcd)[4], int nr_left, int ng_left) {
+    const float2v b2 = {bias, bias};
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
         if (!EDGE || (drd[qq] < nr_left && dcd[qq] < ng_left)) {
+            const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]} + b2);
+            const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]} + b2);
             half4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = half_t(swish_f<false>(acc[4 * qq + r] + bias));
+            o[0] = half_t(y0[0]);
+            o[1] = half_t(y0[1]);
+            o[2] = half_t(y1[0]);
+            o[3] = half_t(y1[1]);
             *reinterpret_cast<half4*>(ep + eoff[qq]) = o;
         }
     }
@@ -149,7 +166,12 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
 
     // ---- expand: tasks (channel tile, strip), a contiguous range per wave --------------------------------------
     const int t_begin = (wave * ntask) / NWAVE, t_end = ((wave + 1) * ntask) / NWAVE;
-    half8 w[KS], a[PF];
+    // activation operands of D tasks are in flight (a ring of D register sets).  Measured: D = 4 / 2 for the shallow
+    // layers (Cin = 16 / 24..40) changes nothing (b2: 59.1 vs 56.1 us at 64 crops) -- the ~0.6 us a task takes there is
+    // not operand latency but the wave's own issue rate (one VALU instruction per ~5 cycles at 2 - 3 waves per SIMD)
+    // plus the exposed FIRST load of the workgroup; so one task ahead it is.
+    constexpr int D = 1;
+    half8 w[KS], aq[D][PF];
     float bias_cur = 0.f;
     auto load_w = [&](int tl) {
 #pragma unroll
@@ -158,21 +180,38 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         bias_cur = (ch < ccur) ? p.be[c0 + ch] : 0.f;
     };
     // (k beyond Cin: the packed weights are zero there, and the 16 bytes past a pixel row are the next pixel's)
-    auto load_a = [&](unsigned off, int ks0) {
+    auto load_a = [&](half8 (&a)[PF], unsigned off, int ks0) {
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if (ks0 + u < KS) a[u] = *reinterpret_cast<const half8*>(xb + off + (ks0 + u) * 32);
     };
-    int tl = 0, rb = 0, cbk = 0;
-    unsigned aoff = 0;
+    STAMP(0);
+    int tl = 0, rb = 0, cbk = 0;                               // the task being computed
+    int ti = t_begin, rbi = 0, cbki = 0;                       // the next task whose operands are requested
+    unsigned aoffq[D];
+    auto issue = [&](int slot) {                               // strip (rbi, cbki) -> ring slot, then step to the next strip
+        if (ti < t_end) {
+            aoffq[slot] = a_offset(rbi, cbki);
+            load_a(aq[slot], aoffq[slot], 0);
+        }
+        ++ti;
+        if (++cbki == nsc) {
+            cbki = 0;
+            if (++rbi == nsr) rbi = 0;                         // (next channel tile: the strips start over)
+        }
+    };
+    const bool fix_l = ex_lo > 0, fix_r = p.EWp > ex_hi;       // (tile touches the left / right image border, or has
+                                                               //  slack groups behind it)
     if (t_begin < t_end) {
         tl = __builtin_amdgcn_readfirstlane(t_begin / nstrip);          // (keeps the loop state in scalar registers)
         const int st = t_begin - tl * nstrip;
         rb = __builtin_amdgcn_readfirstlane(st / nsc);
         cbk = st - rb * nsc;
+        rbi = rb;
+        cbki = cbk;
         load_w(tl);
-        aoff = a_offset(rb, cbk);
-        load_a(aoff, 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d);
     }
     {   // rows of the tile outside the image are 'SAME' zeros of the EXPANDED tensor (top / bottom tiles only)
         const int nz = er_lo + (p.EH - er_hi);
@@ -187,23 +226,29 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         }
     }
 
-    for (int t = t_begin; t < t_end; ++t) {
+    STAMP(1);
+    for (int t0 = t_begin; t0 < t_end; t0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int t = t0 + d;
+        if (t >= t_end) break;                                 // (uniform)
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u], w[u], acc, 0, 0, 0);
+        for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[u], acc, 0, 0, 0);
 #pragma unroll
         for (int ks = PF; ks < KS; ks += PF) {
-            load_a(aoff, ks);
+            load_a(aq[d], aoffq[d], ks);
 #pragma unroll
             for (int u = 0; u < PF; ++u)
-                if (ks + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u], w[ks + u], acc, 0, 0, 0);
+                if (ks + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[ks + u], acc, 0, 0, 0);
         }
-        // this task's place in the tile, then the next task's operands take off
+        // this task's place in the tile; its ring slot is free: the operands of task t + D take off
         const int ch = tl * 32 + lm;
         unsigned char* ep = E + ch * CP + ((ch >> 3) & 1) * 8 + (er_lo + (rb << SRL)) * RP + (g_lo + (cbk << SCL)) * 8;
-        const int nr_left = NR - (rb << SRL), ng_left = NG - (cbk << SCL);
+        unsigned char* ep0 = ep;                               // (row of the strip's corner, at its first group)
+        const int nr_left = NR - (rb << SRL), ng_left = NG - (cbk << SCL), cbk_this = cbk;
         const float bias = bias_cur;
         int tln = tl;
         if (++cbk == nsc) {
@@ -213,18 +258,46 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
                 ++tln;
             }
         }
-        if (t + 1 < t_end) {
-            if (tln != tl) load_w(tln);
-            aoff = a_offset(rb, cbk);
-            load_a(aoff, 0);
-        }
+        issue(d);
+        if (t + 1 < t_end && tln != tl) load_w(tln);           // (rare: at most once or twice per wave)
         tl = tln;
         if (ch < ccur) {
             if (nr_left >= SR && ng_left >= SC) expand_store<false>(acc, bias, ep, eoff, drd, dcd, nr_left, ng_left);
             else expand_store<true>(acc, bias, ep, eoff, drd, dcd, nr_left, ng_left);
         }
+        // 'SAME' zeros inside the rows this task just wrote: the pixels of a border group that lie left / right of the
+        // image were computed from clamped addresses.  The wave that wrote them overwrites them (DS operations of a
+        // wave execute in order: no barrier), lane <-> (channel lm, row g, g + 2, ..) of the strip.
+        if (ch < ccur) {
+            if (fix_l && cbk_this == 0) {                      // (uniform) strip holds the left border group
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) {
+                    const int dr = g + 2 * dd;
+                    if (dr < SR && dr < nr_left) {
+                        half_t* rowp = reinterpret_cast<half_t*>(ep0 + dr * RP) - 4 * g_lo;      // pixel 0 of the tile row
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < ex_lo) rowp[q] = half_t(0);
+                    }
+                }
+            }
+            if (fix_r && cbk_this == nsc - 1) {                // (uniform) strip holds the right border group and beyond
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) {
+                    const int dr = g + 2 * dd;
+                    if (dr < SR && dr < nr_left) {
+                        half_t* rowp = reinterpret_cast<half_t*>(ep0 + dr * RP) - 4 * (g_lo + cbk_this * SC) + ex_hi;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (ex_hi + q < p.EWp) rowp[q] = half_t(0);
+                    }
+                }
+            }
+        }
+      }
     }
 
+    STAMP(2);
     // ---- depthwise taps: items (16-channel block, quad of columns), a contiguous range per wave ---------------
     const int ncb = (ccur + 15) >> 4;
     const int ncol = (p.TH / RL) * p.TXG, ncq = (ncol + 3) >> 2, nitem = ncb * ncq;
@@ -248,31 +321,22 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         load_taps(cb);                                         // in flight across the barrier(s)
     }
     lds_barrier();
-    {   // fix-up: pixels of an in-image row that lie outside the image (the rest of a border group, and the groups
-        // beyond it) are 'SAME' zeros, not expand(0)
-        const int nright = p.EWp - ex_hi;
-        if (ex_lo + nright > 0) {                                // (uniform)
-            const float r_nr = __builtin_amdgcn_rcpf(float(NR));
-            for (int pr = tid; pr < ccur * NR; pr += NTHR) {
-                const int c = fdiv2(pr, r_nr), row = pr - c * NR;
-                half_t* rowp = reinterpret_cast<half_t*>(E + c * CP + ((c >> 3) & 1) * 8 + (er_lo + row) * RP);
-                for (int q = 0; q < ex_lo; ++q) rowp[q] = half_t(0);
-                for (int q = ex_hi; q < p.EWp; ++q) rowp[q] = half_t(0);
-            }
-            lds_barrier();
-        }
-    }
-
+    // (the out-of-image pixels of the rows a wave expanded are zeroed by that wave: see the expand loop)
+    STAMP(3);
     // this lane's first reduce-kernel values (used after the items: see the squeeze-excite half below)
     constexpr int W1V = 16;
     float w1v[W1V];
     {
         const int jo = tid >> 2, q = tid & 3;
-        const float* wrow = p.w1t + size_t(jo < p.R ? jo : 0) * p.Cexp + c0;
 #pragma unroll
-        for (int i = 0; i < W1V; ++i) {
-            const int c = q + 4 * i;
-            w1v[i] = (p.w1t != nullptr && jo < p.R && c < ccur) ? wrow[c] : 0.f;
+        for (int i = 0; i < W1V; ++i) w1v[i] = 0.f;
+        if (p.w1t != nullptr) {                                // (uniform; clamped addresses: no lane predicates)
+            const float* wrow = p.w1t + size_t(jo < p.R ? jo : p.R - 1) * p.Cexp + c0;
+#pragma unroll
+            for (int i = 0; i < W1V; ++i) {
+                const int c = q + 4 * i;
+                w1v[i] = wrow[c < ccur ? c : ccur - 1];
+            }
         }
     }
     unsigned char* stg = smem + p.off_stage + wave * 2048;
@@ -327,19 +391,23 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         const bool okP = colP < ncol && oxP < p.Ho;
         const unsigned obase = (__umul24(unsigned(oy0 + segP * RL + rP), unsigned(p.Ho)) + unsigned(oxP)) * unsigned(p.Cexp) * 2u +
                                unsigned(c0 + cb_this * 16 + hP * 8) * 2u;
-        float sum = 0.f;
+        float2v sum2 = {0.f, 0.f};
+        const float2v m01 = {m[0], m[1]}, m23 = {m[2], m[3]}, bd2 = {bd_this, bd_this};
         unsigned char* sw = stg + j * 32 + cl * 2;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                 // rows 0..3, then rows 4..6, through the 2 KB stage
             const int r0 = half * 4, nr = half ? 3 : 4;
 #pragma unroll
-            for (int r = 0; r < nr; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float y = swish_f<false>(acc[r0 + r][i] + bd_this);
-                    sum = fmaf(y, m[i], sum);
-                    *reinterpret_cast<half_t*>(sw + (r * 4 + i) * 128) = half_t(y);
-                }
+            for (int r = 0; r < nr; ++r) {
+                const float2v y01 = swish2(float2v{acc[r0 + r][0], acc[r0 + r][1]} + bd2);
+                const float2v y23 = swish2(float2v{acc[r0 + r][2], acc[r0 + r][3]} + bd2);
+                sum2 = y01 * m01 + sum2;
+                sum2 = y23 * m23 + sum2;
+                *reinterpret_cast<half_t*>(sw + (r * 4 + 0) * 128) = half_t(y01[0]);
+                *reinterpret_cast<half_t*>(sw + (r * 4 + 1) * 128) = half_t(y01[1]);
+                *reinterpret_cast<half_t*>(sw + (r * 4 + 2) * 128) = half_t(y23[0]);
+                *reinterpret_cast<half_t*>(sw + (r * 4 + 3) * 128) = half_t(y23[1]);
+            }
             wave_lds_sync();
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
@@ -349,11 +417,14 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
             }
             wave_lds_sync();
         }
+        float sum = sum2[0] + sum2[1];
         sum += quad_xor1(sum);                                 // the 4 columns of the quad: (s0 + s1) + (s2 + s3)
         sum += quad_xor2(sum);
         if (j == 0) s_red[cq_this * p.CC + c] = sum;
     }
+    STAMP(4);
     lds_barrier();
+    STAMP(5);
 
     // ---- squeeze-excite, first half (as front.hip): the tile's channel sums, or this workgroup's share of the
     // reduce conv, in a fixed order --------------------------------------------------------------------------
@@ -363,7 +434,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         if (p.w1t == nullptr) p.rpart[(size_t(b) * gridDim.x + tile) * p.Cexp + c0 + tid] = t;
         s_sum[tid] = t;
     }
-    if (p.w1t == nullptr) return;
+    if (p.w1t == nullptr) {
+        STAMP(6);
+        return;
+    }
     lds_barrier();
     {
         // 4 lanes per output j: lane q sums channels q, q+4, ..; combined (a0+a1)+(a2+a3)
@@ -385,6 +459,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
                 p.rpart[((size_t(b) * gridDim.x + tile) * gridDim.y + blockIdx.y) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
         }
     }
+    STAMP(6);
 }
 
 }  // namespace

@@ -228,6 +228,38 @@ int main() {
                 total_bad += check(def, threads == 256 ? "default plan, 256 lanes" : "default plan, 512 lanes");
             }
         }
+#ifdef WHENET_STAMPS
+        {   // phase timeline of the default plan at 256 and 16 crops per launch: per-workgroup stamps (wave 0), averaged
+            for (int n : {256, 16}) {
+                const size_t nwg = size_t(n) * def.ntiles() * def.chunks;
+                long long* d_st; CK(hipMalloc(&d_st, nwg * 8 * sizeof(long long)));
+                CK(hipMemset(d_st, 0, nwg * 8 * sizeof(long long)));
+                a2.n = n; a2.plan = def; a2.plan.threads = 256; a2.wdt = def.xs ? d_wdt2 : d_wdt;
+                launch_front2(a2, st);
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(whenet_stamps), &d_st, sizeof(d_st)));
+                launch_front2(a2, st);
+                CK(hipStreamSynchronize(st));
+                long long* nul = nullptr;
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(whenet_stamps), &nul, sizeof(nul)));
+                std::vector<long long> hs(nwg * 8);
+                CK(hipMemcpy(hs.data(), d_st, hs.size() * sizeof(long long), hipMemcpyDeviceToHost));
+                double ph[6] = {0, 0, 0, 0, 0, 0}, life = 0;
+                long long t0 = hs[0], t1 = 0;
+                for (size_t w = 0; w < nwg; ++w) {
+                    for (int i = 0; i < 6; ++i) ph[i] += double(hs[w * 8 + i + 1] - hs[w * 8 + i]);
+                    life += double(hs[w * 8 + 6] - hs[w * 8]);
+                    t0 = std::min(t0, hs[w * 8]);
+                    t1 = std::max(t1, hs[w * 8 + 6]);
+                }
+                printf("  timeline n=%d (%zu workgroups, kernel span %.1f us): workgroup life %.2f us = prologue %.2f | expand %.2f | "
+                       "barrier+fixup %.2f | taps+epilogue %.2f | barrier %.2f | tail %.2f\n", n, nwg, double(t1 - t0) * 0.01,
+                       life / nwg * 0.01, ph[0] / nwg * 0.01, ph[1] / nwg * 0.01, ph[2] / nwg * 0.01, ph[3] / nwg * 0.01,
+                       ph[4] / nwg * 0.01, ph[5] / nwg * 0.01);
+                CK(hipFree(d_st));
+            }
+        }
+#endif
         const float o256 = time1(256), o64 = time1(64), o16 = time1(16);
         const float n256 = time2(def, 256, 0), n64 = time2(def, 64, 0), n16 = time2(def, 16, 0);
         printf("  round-2 kernel : n=256 %7.2f us  n=64 %7.2f us  n=16 %6.2f us\n", o256, o64, o16);

@@ -1,2 +1,1 @@
-ONLY=b13 timeout 200 ./tools/probes/front2_probe
-WHENET_FRONT_THREADS=256 NOCHECK=1 timeout 300 ./tools/probes/front2_probe
+for s in b2 b3 b4; do ONLY=$s NOCHECK=1 bash tools/probe_pmc.sh $s ./tools/probes/front2_probe > gpurun_out/ppmc_$s.txt 2>&1; done
