@@ -133,6 +133,34 @@ int whenet_create_from_memory(const void* snapshot, size_t nbytes, int device_id
     return create_impl(snapshot, nbytes, device_id, dtype, out);
 }
 
+int whenet_create_postproc(int device_id, whenet_t** out) {
+    if (out == nullptr) {
+        g_create_error = "whenet_create_postproc: NULL argument";
+        return WHENET_EINVAL;
+    }
+    *out = nullptr;
+    try {
+        std::unique_ptr<whenet::Engine> e(new whenet::Engine(device_id));
+        whenet_t* h = new whenet_t;
+        h->engine = e.release();
+        h->device_id = device_id;
+        *out = h;
+        return WHENET_OK;
+    } catch (const whenet::Error& e) {
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_create_error = "out of host memory";
+        return WHENET_ENOMEM;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return WHENET_EHIP;
+    } catch (...) {
+        g_create_error = "unknown error";
+        return WHENET_EHIP;
+    }
+}
+
 void whenet_destroy(whenet_t* h) {
     if (h == nullptr) return;
     try {
@@ -160,6 +188,7 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
         const std::string k = key;
         if (k == "inflight") {
             WHENET_REQUIRE(value >= 1 && value <= MAX_INFLIGHT_ENGINES, WHENET_EINVAL, "inflight must be 1..4");
+            WHENET_REQUIRE(!h->snapshot.empty() || value == 1, WHENET_EINVAL, "inflight: this handle has no network");
             e.release_aux_streams();
             for (whenet::Engine* r : h->replicas) r->release_aux_streams();
             while (int(h->replicas.size()) + 1 > value) {

@@ -75,30 +75,9 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
     params_heads_ = m.params_heads;
     n_tensors_ = m.n_tensors;
 
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        throw Error(WHENET_ENODEV, std::string("no HIP device visible (") + hipGetErrorString(e) +
-                                       "); libwhenet_hip has no CPU fallback");
-    WHENET_REQUIRE(device_id >= 0 && device_id < count, WHENET_ENODEV,
-                   "device_id " + std::to_string(device_id) + " out of range (" + std::to_string(count) + " devices)");
+    open_device(device_id);
     DeviceGuard guard(device_);
-    WHENET_HIP_CHECK(hipGetDeviceProperties(&prop_, device_));
-    WHENET_REQUIRE(std::strstr(prop_.gcnArchName, "gfx950") != nullptr, WHENET_ENODEV,
-                   std::string("device is ") + prop_.gcnArchName + "; this library carries gfx950 code only");
-    num_cus_ = prop_.multiProcessorCount;
-
-    WHENET_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    // Only the main stream exists up front: the runtime places a new stream on its least-loaded
-    // hardware queue (4 of them), so streams are created in the order concurrency needs them -- the
-    // main streams of the engines of one handle, then sub-batch lanes / the copy stream on first use --
-    // instead of nine per engine, most of them idle ballast that skews that placement.
-    WHENET_HIP_CHECK(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
-    for (int i = 0; i < MAX_LANES - 1; ++i) {
-        hipEvent_t ev = nullptr;
-        WHENET_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        join_ev_.push_back(ev);
-    }
+    has_model_ = true;
 
     d_lut_ = static_cast<float*>(upload_bytes(&m.lut[0][0], sizeof(m.lut)));
     d_stem_w_ = upload(m.stem_w);
@@ -147,6 +126,40 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
     WHENET_HIP_CHECK(hipDeviceSynchronize());
 }
 
+void Engine::open_device(int device_id) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw Error(WHENET_ENODEV, std::string("no HIP device visible (") + hipGetErrorString(e) +
+                                       "); libwhenet_hip has no CPU fallback");
+    WHENET_REQUIRE(device_id >= 0 && device_id < count, WHENET_ENODEV,
+                   "device_id " + std::to_string(device_id) + " out of range (" + std::to_string(count) + " devices)");
+    DeviceGuard guard(device_id);
+    WHENET_HIP_CHECK(hipGetDeviceProperties(&prop_, device_id));
+    WHENET_REQUIRE(std::strstr(prop_.gcnArchName, "gfx950") != nullptr, WHENET_ENODEV,
+                   std::string("device is ") + prop_.gcnArchName + "; this library carries gfx950 code only");
+    num_cus_ = prop_.multiProcessorCount;
+
+    WHENET_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    // Only the main stream exists up front: the runtime places a new stream on its least-loaded
+    // hardware queue (4 of them), so streams are created in the order concurrency needs them -- the
+    // main streams of the engines of one handle, then sub-batch lanes / the copy stream on first use --
+    // instead of nine per engine, most of them idle ballast that skews that placement.
+    WHENET_HIP_CHECK(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+    for (int i = 0; i < MAX_LANES - 1; ++i) {
+        hipEvent_t ev = nullptr;
+        WHENET_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        join_ev_.push_back(ev);
+    }
+}
+
+// A handle without a network: what whenet_yolo_eval / whenet_op_crop_resize need (device, stream, scratch).
+Engine::Engine(int device_id) : device_(device_id), dtype_(WHENET_F32) { open_device(device_id); }
+
+void Engine::require_model() const {
+    WHENET_REQUIRE(has_model_, WHENET_EINVAL, "this handle was created without a network (whenet_create_postproc)");
+}
+
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
@@ -169,7 +182,7 @@ Engine::~Engine() {
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
     }
-    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, hcount_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_};
+    void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, hcount_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_, yolo_scratch_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
     for (void* p : weight_allocs_) (void)hipFree(p);
@@ -706,6 +719,7 @@ void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_am
 void Engine::forward_device(const uint8_t* d_crops, int n, float* d_ypr, int32_t* d_argmax, float* d_logits,
                             hipStream_t stream) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(d_crops != nullptr && d_ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
     WHENET_REQUIRE((reinterpret_cast<uintptr_t>(d_crops) & 3) == 0, WHENET_EINVAL, "crops must be 4-byte aligned");
     ensure_capacity(n);
@@ -714,6 +728,7 @@ void Engine::forward_device(const uint8_t* d_crops, int n, float* d_ypr, int32_t
 
 void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(crops != nullptr && ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
     ensure_capacity(n);
     const size_t N = size_t(n);
@@ -731,6 +746,7 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
 // Eager launches (no graph): a compatibility path, not the one bench.py times.
 void Engine::forward_host_f32(const float* x, int n, float* ypr, int32_t* argmax, float* logits) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(x != nullptr && ypr != nullptr, WHENET_EINVAL, "image and ypr must not be NULL");
     ensure_capacity(n);
     const size_t N = size_t(n);
@@ -795,6 +811,7 @@ void Engine::ensure_slot(Slot& s, int n) {
 
 int Engine::submit(const uint8_t* crops, int n) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(crops != nullptr, WHENET_EINVAL, "crops must not be NULL");
     Slot* slot = nullptr;
     for (Slot& s : slots_)
@@ -875,6 +892,7 @@ void check_rects(int fh, int fw, const int32_t* rects, int k) {
 // cropped / colour-swapped / resized on the device (frame.hip) straight into the forward's input.
 int Engine::submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(frame != nullptr && fh > 0 && fw > 0 && k >= 0 && (k == 0 || rects != nullptr), WHENET_EINVAL,
                    "submit_frame: bad arguments");
     check_rects(fh, fw, rects, k);
@@ -945,7 +963,7 @@ int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* g
                    "yolo_eval: 3 maps with 9 anchors or 2 maps with 6 (model.py:203)");
     WHENET_REQUIRE(num_classes >= 1 && num_classes <= 1024 && image_h > 0 && image_w > 0, WHENET_EINVAL,
                    "yolo_eval: bad num_classes / image shape");
-    WHENET_REQUIRE(max_boxes >= 1 && max_boxes <= yolo_max_select(), WHENET_EINVAL, "yolo_eval: max_boxes must be 1..256");
+    WHENET_REQUIRE(max_boxes >= 1, WHENET_EINVAL, "yolo_eval: max_boxes must be >= 1");      // (any value, as model.py:193)
     // model.py:203: anchor_mask = [[6,7,8],[3,4,5],[0,1,2]] for 3 maps, [[3,4,5],[1,2,3]] for 2
     static const int ANCHOR_MASK3[3][3] = {{6, 7, 8}, {3, 4, 5}, {0, 1, 2}};
     static const int ANCHOR_MASK2[2][3] = {{3, 4, 5}, {1, 2, 3}};
@@ -968,10 +986,21 @@ int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* g
     }
     a.score_thr = score_threshold;
     a.iou_thr = iou_threshold;
-    a.max_boxes = max_boxes;
-    TempBufs tmp;
+    // one engine-owned scratch block, grown on demand (round 2 paid ~10 hipMalloc/hipFree per frame here)
+    struct Carver {
+        Engine* e;
+        size_t used = 0;
+        std::vector<std::pair<size_t, size_t>> pieces;           // (offset, bytes)
+        size_t add(size_t nbytes) {
+            const size_t off = (used + 255) & ~size_t(255);
+            used = off + (nbytes ? nbytes : 16);
+            return off;
+        }
+    };
     int N = 0;
     const size_t per = size_t(5 + num_classes) * 3;
+    size_t feat_off[3] = {0, 0, 0}, feat_bytes[3] = {0, 0, 0};
+    Carver cv{this};
     for (int l = 0; l < num_layers; ++l) {
         WHENET_REQUIRE(feats[l] && grid_h[l] > 0 && grid_w[l] > 0 && grid_h[l] <= 4096 && grid_w[l] <= 4096, WHENET_EINVAL,
                        "yolo_eval: bad feature map");
@@ -984,24 +1013,47 @@ int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* g
             L.anchor[k][0] = anchors[2 * m];
             L.anchor[k][1] = anchors[2 * m + 1];
         }
-        const size_t bytes = size_t(L.gh) * L.gw * per * sizeof(float);
-        float* d = static_cast<float*>(tmp.get(bytes));
-        WHENET_HIP_CHECK(hipMemcpyAsync(d, feats[l], bytes, hipMemcpyHostToDevice, stream_));
-        L.feats = d;
+        feat_bytes[l] = size_t(L.gh) * L.gw * per * sizeof(float);
+        feat_off[l] = cv.add(feat_bytes[l]);
         N += L.gh * L.gw * 3;
     }
     a.N = N;
     a.NP = 1;
     while (a.NP < N) a.NP <<= 1;
+    if (max_boxes > N) max_boxes = N;                       // (no more selections than boxes)
+    a.max_boxes = max_boxes;
     const size_t C = size_t(num_classes), MB = size_t(max_boxes);
-    a.boxes = static_cast<float*>(tmp.get(size_t(N) * 4 * sizeof(float)));
-    a.all_scores = all_scores ? static_cast<float*>(tmp.get(size_t(N) * C * sizeof(float))) : nullptr;
-    a.counts = static_cast<int*>(tmp.get(C * sizeof(int)));
-    a.keys = static_cast<unsigned long long*>(tmp.get(C * size_t(a.NP) * sizeof(unsigned long long)));
-    a.out_boxes = static_cast<float*>(tmp.get(C * MB * 4 * sizeof(float)));
-    a.out_scores = static_cast<float*>(tmp.get(C * MB * sizeof(float)));
-    a.out_index = static_cast<int*>(tmp.get(C * MB * sizeof(int)));
-    a.out_count = static_cast<int*>(tmp.get(C * sizeof(int)));
+    const size_t o_boxes = cv.add(size_t(N) * 4 * sizeof(float));
+    const size_t o_all = all_scores ? cv.add(size_t(N) * C * sizeof(float)) : 0;
+    const size_t o_counts = cv.add(C * sizeof(int));
+    const size_t o_keys = cv.add(C * size_t(a.NP) * sizeof(unsigned long long));
+    const size_t o_ob = cv.add(C * MB * 4 * sizeof(float));
+    const size_t o_os = cv.add(C * MB * sizeof(float));
+    const size_t o_oi = cv.add(C * MB * sizeof(int));
+    const size_t o_oc = cv.add(C * sizeof(int));
+    if (cv.used > yolo_scratch_bytes_) {
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+        if (yolo_scratch_) (void)hipFree(yolo_scratch_);
+        yolo_scratch_ = nullptr;
+        yolo_scratch_bytes_ = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&yolo_scratch_), cv.used);
+        if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("yolo_eval scratch: ") + hipGetErrorString(e));
+        yolo_scratch_bytes_ = cv.used;
+    }
+    unsigned char* base = yolo_scratch_;
+    for (int l = 0; l < num_layers; ++l) {
+        float* d = reinterpret_cast<float*>(base + feat_off[l]);
+        WHENET_HIP_CHECK(hipMemcpyAsync(d, feats[l], feat_bytes[l], hipMemcpyHostToDevice, stream_));
+        a.layer[l].feats = d;
+    }
+    a.boxes = reinterpret_cast<float*>(base + o_boxes);
+    a.all_scores = all_scores ? reinterpret_cast<float*>(base + o_all) : nullptr;
+    a.counts = reinterpret_cast<int*>(base + o_counts);
+    a.keys = reinterpret_cast<unsigned long long*>(base + o_keys);
+    a.out_boxes = reinterpret_cast<float*>(base + o_ob);
+    a.out_scores = reinterpret_cast<float*>(base + o_os);
+    a.out_index = reinterpret_cast<int*>(base + o_oi);
+    a.out_count = reinterpret_cast<int*>(base + o_oc);
     launch_yolo_eval(a, stream_);
     std::vector<float> hb(C * MB * 4), hs(C * MB);
     std::vector<int> hi(C * MB), hc(C);
@@ -1032,6 +1084,7 @@ int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* g
 // chains and the iterations; bytes / flops are those of ONE chain's launch (its sub-batch).
 int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(d_crops != nullptr && iters >= 1, WHENET_EINVAL, "profile: bad arguments");
     ensure_capacity(n);
     int lanes = lanes_;
@@ -1107,6 +1160,7 @@ int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat
 // ------------------------------------------------------------------------------------------
 void Engine::op_stem(const uint8_t* crops, int n, float* out) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(crops && out, WHENET_EINVAL, "op_stem: NULL argument");
     ensure_capacity(n);
     TempBufs tmp;
@@ -1122,6 +1176,7 @@ void Engine::op_stem(const uint8_t* crops, int n, float* out) {
 
 void Engine::op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(index >= 1 && index <= int(blocks_.size()), WHENET_EINVAL, "op_block: index must be 1..16");
     WHENET_REQUIRE(in != nullptr, WHENET_EINVAL, "op_block: NULL input");
     ensure_capacity(n);
@@ -1154,6 +1209,7 @@ void Engine::op_block(int index, const float* in, int n, float* expand_out, floa
 
 void Engine::op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(in != nullptr, WHENET_EINVAL, "op_head: NULL input");
     ensure_capacity(n);
     const size_t N = size_t(n);
@@ -1196,6 +1252,7 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
 
 void Engine::op_decode(const float* logits, int n, float* ypr, int32_t* argmax) {
     DeviceGuard guard(device_);
+    require_model();
     WHENET_REQUIRE(logits && ypr, WHENET_EINVAL, "op_decode: NULL argument");
     ensure_capacity(n);
     const size_t N = size_t(n);

@@ -63,6 +63,7 @@ constexpr int MAX_LANES = 8;
 class Engine {
   public:
     Engine(const void* snapshot, size_t nbytes, int device_id, int dtype);
+    explicit Engine(int device_id);      // no network: device + stream + scratch for the frame / detector stages only
     ~Engine();
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
@@ -147,6 +148,9 @@ class Engine {
     void ensure_slot_frame(Slot& s, size_t frame_bytes, int k);
     Slot* free_slot();
 
+    void open_device(int device_id);
+    void require_model() const;
+    bool has_model_ = false;
     int device_ = 0, dtype_ = WHENET_F32, num_cus_ = 256;
     bool use_graph_ = true;
     int pw_impl_ = 0;
@@ -186,6 +190,8 @@ class Engine {
     int32_t* o_amax_ = nullptr;
     float* o_logits_ = nullptr;
     size_t partial_per_crop_ = 0;
+    unsigned char* yolo_scratch_ = nullptr;      // device scratch of yolo_eval, grown on demand
+    size_t yolo_scratch_bytes_ = 0;
 
     std::map<GraphKey, hipGraphExec_t> graphs_;
 

@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
         else raw[i] = ok ? in32[iy * ROW_DWORDS + j] : 0u;
     }
     auto pack = [](float v) -> uint32_t {
+        // hi + lo in binary16 (22 bits kept).  Real-valued input beyond the binary16 range saturates at +-65504
+        // (a normalised pixel of that size is ~3.7 million grey levels): without the clamp hi = inf, lo = nan
+        if constexpr (INF32) v = fminf(fmaxf(v, -65504.0f), 65504.0f);
         const half_t hi = half_t(v), lo = half_t(v - float(hi));
         return uint32_t(__builtin_bit_cast(unsigned short, hi)) | (uint32_t(__builtin_bit_cast(unsigned short, lo)) << 16);
     };

@@ -128,19 +128,33 @@ __global__ __launch_bounds__(NMS_THREADS) void whenet_yolo_nms_kernel(YoloArgs a
         const int idx = int(0xffffffffu - unsigned(key & 0xffffffffull));
         const float4 box = boxes[idx];
         bool sup = false;
-        for (int j = tid; j < nsel; j += 64) sup = sup || (iou_tf(box, s_sel[j]) > a.iou_thr);
+        for (int j = tid; j < nsel; j += 64) {
+            float4 sj;
+            if (j < NMS_MAX_SELECT) {
+                sj = s_sel[j];
+            } else {                                      // beyond the LDS list: the output array itself, read from L2
+                sj.x = __hip_atomic_load(ob + j * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sj.y = __hip_atomic_load(ob + j * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sj.z = __hip_atomic_load(ob + j * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sj.w = __hip_atomic_load(ob + j * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sup = sup || (iou_tf(box, sj) > a.iou_thr);
+        }
         if (__ballot(sup) == 0ull) {
             if (tid == 0) {
-                s_sel[nsel] = box;
-                ob[nsel * 4 + 0] = box.x;
-                ob[nsel * 4 + 1] = box.y;
-                ob[nsel * 4 + 2] = box.z;
-                ob[nsel * 4 + 3] = box.w;
+                if (nsel < NMS_MAX_SELECT) s_sel[nsel] = box;
+                __hip_atomic_store(ob + nsel * 4 + 0, box.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ob + nsel * 4 + 1, box.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ob + nsel * 4 + 2, box.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ob + nsel * 4 + 3, box.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 os[nsel] = __uint_as_float(unsigned(key >> 32));
                 oi[nsel] = idx;
             }
             ++nsel;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the new box is visible to the wave's next reads
+            // the new box is visible to the wave's next reads (LDS list; beyond it the write-through stores have
+            // reached L2 before the L2 loads above are issued)
+            if (nsel > NMS_MAX_SELECT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     if (tid == 0) a.out_count[c] = nsel;
@@ -151,8 +165,8 @@ __global__ __launch_bounds__(NMS_THREADS) void whenet_yolo_nms_kernel(YoloArgs a
 int yolo_max_select() { return NMS_MAX_SELECT; }
 
 void launch_yolo_eval(const YoloArgs& a, hipStream_t stream) {
-    WHENET_REQUIRE(a.N > 0 && a.num_classes > 0 && a.max_boxes > 0 && a.max_boxes <= NMS_MAX_SELECT, WHENET_EINVAL,
-                   "yolo_eval: bad sizes (max_boxes must be 1..256)");
+    WHENET_REQUIRE(a.N > 0 && a.num_classes > 0 && a.max_boxes > 0 && a.max_boxes <= a.N, WHENET_EINVAL,
+                   "yolo_eval: bad sizes (max_boxes must be 1..number of boxes)");
     WHENET_HIP_CHECK(hipMemsetAsync(a.counts, 0, size_t(a.num_classes) * sizeof(int), stream));
     hipLaunchKernelGGL(whenet_yolo_decode_kernel, dim3((a.N + 255) / 256), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(whenet_yolo_nms_kernel, dim3(a.num_classes), dim3(NMS_THREADS), 0, stream, a);

@@ -37,6 +37,7 @@ _P = C.c_void_p
 _PROTOS = {
     "whenet_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "whenet_create_from_memory": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
+    "whenet_create_postproc": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "whenet_destroy": (None, [_P]),
     "whenet_last_error": (C.c_char_p, [_P]),
     "whenet_get_info": (C.c_int, [_P, C.POINTER(Info)]),
@@ -169,6 +170,22 @@ class Handle:
         self.dtype = dtype
         self.device = device
 
+    @classmethod
+    def postproc(cls, device: int = 0) -> "Handle":
+        """A handle WITHOUT a network (whenet_create_postproc): device, stream and scratch for the frame / detector
+        stages (yolo_eval, op_crop_resize); forwards raise."""
+        lib = load()
+        h = _P()
+        rc = lib.whenet_create_postproc(device, C.byref(h))
+        if rc != OK:
+            raise_for(rc, (lib.whenet_last_error(None) or b"").decode(errors="replace"))
+        self = cls.__new__(cls)
+        self._h = h
+        self._lib = lib
+        self.dtype = F32
+        self.device = device
+        return self
+
     def _check(self, rc: int):
         if rc != OK:
             raise_for(rc, (self._lib.whenet_last_error(self._h) or b"").decode(errors="replace"))
@@ -273,7 +290,9 @@ class Handle:
         gh = np.array([m.shape[0] for m in maps], np.int32)
         gw = np.array([m.shape[1] for m in maps], np.int32)
         n_all = int(sum(m.shape[0] * m.shape[1] * 3 for m in maps))
-        cap = num_classes * max_boxes
+        if max_boxes < 1:
+            raise ValueError("yolo_eval: max_boxes must be >= 1")
+        cap = num_classes * min(int(max_boxes), n_all)          # (no more selections per class than boxes)
         boxes = np.empty((cap, 4), np.float32)
         scores = np.empty(cap, np.float32)
         classes = np.empty(cap, np.int32)

@@ -13,8 +13,9 @@
  *     whenet_last_error() gives the message for the last failure on that handle
  *     (or, with a NULL handle, of the last failed whenet_create* on this thread);
  *   - all outputs are caller-allocated; inputs are never written;
- *   - a handle owns one device, one stream, its device weights and activation arena, and is
- *     NOT thread-safe: use one handle per host thread / per GPU;
+ *   - a handle owns one device and 1..4 ENGINES (option "inflight", default 1), each engine with its own main
+ *     stream, lane / copy streams created on demand, activation arena, hipGraphs and a copy of the device weights;
+ *     a handle is NOT thread-safe: use one handle per host thread / per GPU;
  *   - crops are uint8 RGB, NHWC, [n,224,224,3] contiguous -- exactly the array the
  *     reference's callers build (demo.py:8-12, demo_video.py:21-24);
  *   - there is no CPU fallback anywhere in this library: without a gfx950 device
@@ -86,6 +87,9 @@ typedef struct whenet_launch_stat {
 WHENET_API int whenet_create(const char* snapshot_path, int device_id, int dtype, whenet_t** out);
 WHENET_API int whenet_create_from_memory(const void* snapshot, size_t nbytes, int device_id, int dtype,
                               whenet_t** out);
+/* A handle WITHOUT a network: device, stream and scratch for the frame / detector stages only
+ * (whenet_yolo_eval, whenet_op_crop_resize, whenet_frame_rects); every forward entry point returns WHENET_EINVAL. */
+WHENET_API int whenet_create_postproc(int device_id, whenet_t** out);
 WHENET_API void whenet_destroy(whenet_t* h);
 WHENET_API const char* whenet_last_error(const whenet_t* h);
 WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
@@ -123,7 +127,8 @@ WHENET_API int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n,
  * the reference hands to Model.predict (whenet.py:27) -- i.e. (img/255 - mean)/std computed by
  * the caller as whenet.py:23-26 does (float64, then cast).  whenet.py:25 divides any numeric array
  * by 255, so crops that are not 8-bit integers (no byte LUT applies) take this entry point; the
- * drop-in get_angle routes them here.  Host pointers, blocking, eager launches. */
+ * drop-in get_angle routes them here.  Host pointers, blocking, eager launches.  An f16 handle computes in
+ * binary16 activations: normalised inputs beyond +-65504 saturate there (an f32 handle takes any finite float32). */
 WHENET_API int whenet_forward_f32(whenet_t* h, const float* image, int n,
                        float* ypr, int32_t* argmax, float* logits);
 
@@ -179,7 +184,8 @@ WHENET_API int whenet_op_crop_resize(whenet_t* h, const uint8_t* frame, int fram
  *                (batch of one, as YOLO.detect feeds it), coarsest map first like the Keras model's outputs
  *   anchors      num_anchors x (w, h) as in yolo_anchors.txt; 3 maps need 9 anchors, 2 maps ("tiny") 6
  *   image_h/w    size of the original image (`input_image_shape`); the network input is 32 x the first map's grid
- *   max_boxes    per class, 1..256 (reference default 20); score: `>= score_threshold`; NMS drops IoU `> iou_threshold`
+ *   max_boxes    per class, any value >= 1 as the reference (default 20; more than 256 selections per class spill from
+ *                LDS to the output array); score: `>= score_threshold`; NMS drops IoU `> iou_threshold`
  *   boxes        float [num_classes*max_boxes][4]  y_min, x_min, y_max, x_max in image pixels (not clipped, as the reference)
  *   scores, classes, index (may be NULL: the box's position in the concatenated (map, y, x, anchor) list)
  *   count        number of detections written, class by class, descending score inside a class

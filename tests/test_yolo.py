@@ -114,8 +114,12 @@ def test_gpu_yolo_eval_edges(gpu_handle):
     # argument errors
     with pytest.raises(ValueError):
         gpu_handle.yolo_eval(maps, synth.YOLO_ANCHORS[:6], 1, IMAGE)
+    # any max_boxes, as the reference: more than 256 selections per class spill from LDS to the output array
+    # (every box passes, nothing overlaps enough to be suppressed at IoU 0.999 -> hundreds of detections)
+    assert _compare(gpu_handle, maps, synth.YOLO_ANCHORS, 1, IMAGE, max_boxes=1000, score_threshold=0.0, iou_threshold=0.999) > 256
+    assert _compare(gpu_handle, maps, synth.YOLO_ANCHORS, 1, IMAGE, max_boxes=10 ** 7, score_threshold=0.3, iou_threshold=0.45) > 0
     with pytest.raises(ValueError):
-        gpu_handle.yolo_eval(maps, synth.YOLO_ANCHORS, 1, IMAGE, max_boxes=1000)
+        gpu_handle.yolo_eval(maps, synth.YOLO_ANCHORS, 1, IMAGE, max_boxes=0)
     with pytest.raises(ValueError):
         gpu_handle.yolo_eval(maps, synth.YOLO_ANCHORS, 2, IMAGE)
 
@@ -127,3 +131,8 @@ def test_gpu_yolo_drop_in_signature(gpu_handle):
     b, s, c = yolo.yolo_eval(maps, synth.YOLO_ANCHORS, 1, IMAGE, score_threshold=0.3, iou_threshold=0.45, handle=gpu_handle)
     rb, rs, rc = Y.yolo_eval([m[0] for m in maps], synth.YOLO_ANCHORS, 1, IMAGE, score_threshold=0.3, iou_threshold=0.45)
     assert b.shape == rb.shape and np.allclose(b, rb, rtol=1e-5, atol=1.0) and list(c) == list(rc)
+    # without a handle: the module's network-less post-processing handle (whenet_create_postproc), same result
+    b2, s2, c2 = yolo.yolo_eval(maps, synth.YOLO_ANCHORS, 1, IMAGE, score_threshold=0.3, iou_threshold=0.45)
+    assert np.array_equal(b2, b) and np.array_equal(s2, s)
+    with pytest.raises(ValueError):                               # such a handle has no network to run
+        yolo._handle(0).forward(np.zeros((1, 224, 224, 3), np.uint8))

@@ -4,7 +4,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 i=0
 for OPT in "$@"; do
   i=$((i+1))
-  ARGS=""; for kv in $OPT; do ARGS="$ARGS --opt $kv"; done
+  ARGS=""; LIBV=""; for kv in $OPT; do case $kv in lib=*) LIBV=$R/headposeestimation-whenet_amd/lib/variants/lib_${kv#lib=}.so;; *) ARGS="$ARGS --opt $kv";; esac; done
+  if [ -n "$LIBV" ]; then export WHENET_HIP_LIB=$LIBV; else unset WHENET_HIP_LIB; fi
   timeout 300 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency --no-sweep $ARGS --dump-layers $R/gpurun_out/ab_layers_$i.json > $R/gpurun_out/ab_bench_$i.json 2>/dev/null
   python - "$R/gpurun_out/ab_bench_$i.json" "$OPT" <<'PY'
 import json,sys

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 DT=${1:-f16}; B=${2:-64}
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --dtype $DT --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-serial --profile-iters 1 --no-graph"
+CMD="python $R/bench.py --dtype $DT --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-serial --no-sweep --no-repeat --profile-iters 1 --no-graph"
 i=0
 for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" \

@@ -18,7 +18,7 @@ _cache = {}
 def demangle_whenet(n):
     """rocprofv3 / llvm-cxxfilt leave the _Float16 instantiations mangled (DF16_): decode the
     simple template argument lists of this library's kernels by hand."""
-    m = re.search(r"\d+(whenet_[a-z_]+?)I((?:DF16_|f|L[ib]\d+E)+)E", n)
+    m = re.search(r"\d+(whenet_[a-z_0-9]+?)I((?:DF16_|f|L[ib]\d+E)+)E", n)
     if not m:
         return None
     args = []
@@ -87,7 +87,11 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"]):
     out[k] = {"mfma_busy_cycles": mfma_busy, "busy_cu_cycles": busy_cu,
               "mfma_util_of_busy_cu": (mfma_busy / (4 * busy_cu)) if busy_cu else None,
               "dispatches_seen": a["tn"], "avg_us_under_pmc": a["t"] / max(a["tn"], 1), "hbm_bytes_per_launch": fetch + write,
-              "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write}
+              "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+              "valu_active_pct_of_wave_cycles": 100 * avg(a, "SQ_ACTIVE_INST_VALU") / wc,
+              "valu_insts_per_wave": avg(a, "SQ_INSTS_VALU") / waves,
+              "mfma_busy_pct_of_cu_cycles": (100 * mfma_busy / (4 * busy_cu)) if busy_cu else None,
+              "lds_bank_conflict_pct": 100 * avg(a, "SQ_LDS_BANK_CONFLICT") / (avg(a, "SQ_ACTIVE_INST_LDS") or 1)}
 # Matrix-core occupancy per kernel (pass 6).  SQ_VALU_MFMA_BUSY_CYCLES counts cycles a SIMD's MFMA pipe is
 # busy (32 per v_mfma_f32_32x32x16_f16), summed over the chip; SQ_BUSY_CU_CYCLES counts cycles a CU has a wave,
 # summed over CUs; a CU has 4 SIMDs -> util = mfma_busy / (4 * busy_cu).
