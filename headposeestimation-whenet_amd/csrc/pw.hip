@@ -45,7 +45,9 @@ namespace {
 //     activation rows, gate) are issued before the MFMAs of the current one, so a wave always has one
 //     group in flight while it multiplies (the kernel is latency-bound otherwise: few rows, deep K);
 //   * the SE gate multiplies the activation fragment as a T x T product (one packed multiply per two
-//     halfs; se.hip stores the gate in T);
+//     halfs; se.hip stores the gate in T).  Round 3: the gate rows of the <= 3 crops a workgroup's rows belong to
+//     are staged ONCE in LDS (<= 6.9 KB) instead of being fetched per pixel row and k-step from global memory -- that
+//     fetch was a third of the workgroup's operand bytes, and a CU pulls only ~50 GB/s from L2 (same bits);
 //   * the combine is spread over the 4 waves: wave p owns a quarter of the accumulators (B2 = 2: one of
 //     the four tiles; B2 = 1: four consecutive out-channels), receives the other three waves' share of it
 //     through LDS and runs bias / skip / store for it.
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     constexpr int U = (B2 == 2) ? 2 : 4;            // k-steps per load group; two groups are in flight
     constexpr int NACC = MB * NT * 16, SL = NACC / 4;
     __shared__ float s_red[4 * 3 * SL * 64];        // [owner][source (3 others)][SL][lane]
+    constexpr int GCROPS = MB + 1, GK = 1152;       // crops a workgroup's MB*32 rows can touch (HW >= 49), max K
+    __shared__ __attribute__((aligned(16))) T s_gate[GATE ? GCROPS * GK : 8];
 
     const int id = blockIdx.x;
     const int q = id >> 3;
@@ -73,14 +77,24 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     const int g = lane >> 5;
     bool rvalid[MB];
     const T* ap[MB];
-    const T* gp[MB];
+    const T* gp[MB];                                // (LDS) this lane's row of the staged gate, per row block
+    const int row_first = mt * MB * 32;
+    const int crop_lo = row_first / HW;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int row = (mt * MB + mb) * 32 + (lane & 31);
         rvalid[mb] = row < M;
         const int rowc = rvalid[mb] ? row : (M - 1);
         ap[mb] = A + size_t(rowc) * K + g * V;
-        gp[mb] = GATE ? gate + size_t(rowc / HW) * K + g * V : nullptr;
+        gp[mb] = GATE ? s_gate + (rowc / HW - crop_lo) * K + g * V : nullptr;
+    }
+    if constexpr (GATE) {
+        // gate rows of crops crop_lo .. crop_hi -> LDS, 16 bytes per lane (K is a multiple of 16)
+        const int row_last = (row_first + MB * 32 < M ? row_first + MB * 32 : M) - 1;
+        const int ncrop = row_last / HW - crop_lo + 1;                 // <= GCROPS
+        const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
+        VT* dst = reinterpret_cast<VT*>(s_gate);
+        for (int i = threadIdx.x; i < ncrop * K / V; i += 256) dst[i] = src[i];
     }
     const VT* wp = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64 + lane;
 
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
             for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.0f;
 
     struct Ops {
-        VT a[U][MB], g[U][MB], w[U][NT];
+        VT a[U][MB], w[U][NT];
     };
     auto issue = [&](int ks, Ops& o) {
 #pragma unroll
@@ -107,18 +121,19 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
             for (int mb = 0; mb < MB; ++mb) {
                 const bool la = ok && rvalid[mb] && k1 * 2 * V + g * V < K;
                 o.a[u][mb] = la ? *reinterpret_cast<const VT*>(ap[mb] + k1 * 2 * V) : vec_zero<T>();
-                if constexpr (GATE)
-                    o.g[u][mb] = la ? *reinterpret_cast<const VT*>(gp[mb] + k1 * 2 * V) : vec_zero<T>();
             }
         }
     };
-    auto compute = [&](const Ops& o) {
+    auto compute = [&](const Ops& o, int ks) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 VT a = o.a[u][mb];
-                if constexpr (GATE) a = a * o.g[u][mb];
+                if constexpr (GATE) {                                      // (rows past M / k past K: a is zero)
+                    const int k1 = ks + u * SK;
+                    if (k1 < KS) a = a * *reinterpret_cast<const VT*>(gp[mb] + k1 * 2 * V);
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     if (nt0 + t < NTILES) Mfma<T>::step(o.w[u][t], a, acc[mb][t]);
@@ -127,11 +142,12 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
 
     Ops o0, o1;
     issue(kpart, o0);
+    if constexpr (GATE) lds_barrier();              // the staged gate is complete (its global loads were issued first)
     for (int ks = kpart; ks < KS; ks += 2 * U * SK) {
         issue(ks + U * SK, o1);
-        compute(o0);
+        compute(o0, ks);
         issue(ks + 2 * U * SK, o0);
-        if (ks + U * SK < KS) compute(o1);
+        if (ks + U * SK < KS) compute(o1, ks + U * SK);
     }
 
     // ---- combine: wave p owns accumulators [p*SL, (p+1)*SL) of the flattened (mb, t, r) index -----
@@ -511,6 +527,8 @@ void launch_dtype(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
 
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream) {
     WHENET_REQUIRE(a.N % 4 == 0 && a.M > 0, WHENET_EINVAL, "pointwise: bad shape");
+    WHENET_REQUIRE(a.gate == nullptr || a.K < 320 || (a.K <= 1152 && a.K % 16 == 0 && a.HW >= 49), WHENET_EINVAL,
+                   "pointwise: gated deep contraction outside the staged-gate limits (K <= 1152, K % 16 == 0, HW >= 49)");
     if (dtype == WHENET_F16) launch_dtype<half_t>(a, impl, num_cus, stream);
     else launch_dtype<float>(a, impl, num_cus, stream);
     WHENET_HIP_CHECK(hipGetLastError());
