@@ -206,6 +206,11 @@ void Engine::set_option(const std::string& key, long value) {
         fuse_front_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "se_fuse") {
+        WHENET_REQUIRE(value >= 0 && value <= 2, WHENET_EINVAL, "se_fuse must be 0 (never), 1 (where it pays) or 2 (always)");
+        se_fuse_ = int(value);
+        sync();
+        drop_graphs();
     } else if (key == "front_impl") {
         WHENET_REQUIRE(value >= 0 && value <= 2, WHENET_EINVAL,
                        "front_impl must be 0 (front.hip everywhere), 1 (per layer, default) or 2 (front2.hip everywhere, f16)");
@@ -256,8 +261,12 @@ void Engine::get_info(whenet_info_t* out) const {
             const bool has_expand = b.spec.expand != 1;
             const bool front = fuse_front_ && has_expand;
             k += front ? 1 : (has_expand ? 2 : 1);
-            (void)front;
-            k += 2;
+            {   // (project alone when it computes the gate itself: the rule of enqueue_block)
+                const bool f2 = dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
+                const int np = f2 ? b.f2plan.ntiles() * b.f2plan.chunks : b.fplan.ntiles() * b.fplan.chunks;
+                const bool pays = b.project.K < 320 && np <= 24;
+                k += (front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && pays))) ? 1 : 2;
+            }
         }
         out->n_kernels_per_forward = k;
     }
@@ -381,8 +390,8 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.bd = b.dw.bias;
         a.out = v.d;
         a.rpart = v.partial;
-        se_in_front = b.se.C >= 480;         // blocks 7-16: the SE reduce conv moves into the front kernel
-        a.w1t = se_in_front ? b.se.w1t : nullptr;
+        se_in_front = true;                  // the SE reduce conv is applied by the front kernel to its channel sums
+        a.w1t = b.se.w1t;
         a.R = b.se.R;
         a.k = sp.k;
         a.s = sp.s;
@@ -410,8 +419,8 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.bd = b.dw.bias;
         a.out = v.d;
         a.rpart = v.partial;
-        se_in_front = b.se.C >= 480;         // blocks 7-16: the SE reduce conv moves into the front kernel
-        a.w1t = se_in_front ? b.se.w1t : nullptr;
+        se_in_front = true;                  // the SE reduce conv is applied by the front kernel to its channel sums
+        a.w1t = b.se.w1t;
         a.R = b.se.R;
         a.k = sp.k;
         a.s = sp.s;
@@ -465,7 +474,28 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         R(p + "/dw", "dw", kernel_name_dw(dtype_, sp.k, sp.s), double(n) * (hw_in + hw_out) * cexp * es,
           2.0 * n * hw_out * sp.k * sp.k * cexp, [&] { launch_dw(a, dtype_, s); });
     }
-    if (se_in_front) {
+    // Second half of the SEBlock.  Where it pays, the project GEMM's workgroups compute the gate of their own rows'
+    // crops from the front kernel's partial vectors in their prologue (se_device.h; no launch, the gate never reaches
+    // HBM); otherwise a stand-alone launch writes the gate.  Measured per block at 64 crops (tools/ab_layers.sh,
+    // se_fuse=2 against 0): every workgroup has to pull the WHOLE excite kernel (K x R floats) and all partial vectors
+    // of its crops, so the prologue costs +1 us for blocks 4-6 (<= 12 KB, <= 20 vectors: a 7-8 us launch saved), +7 /
+    // +12 us for blocks 3 / 2 (40 / 48 partial vectors: three dependent round trips), +4..9 us for the 14x14 blocks
+    // (38-75 KB: break-even) and +24 us for the 7x7 blocks (221 KB per workgroup at ~50 GB/s per CU).  The bits are
+    // the same either way.  Option se_fuse: 0 = never, 1 = where it pays (default), 2 = every fused-front block.
+    const int se_np = se_ntiles * se_chunks;
+    const bool se_pays = b.project.K < 320 && se_np <= 24;
+    const bool se_fused = se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && se_pays));
+    SeFuse sef{};
+    if (se_fused) {
+        sef.rpart = v.partial;
+        sef.b1 = b.se.b1;
+        sef.w2c = b.se.w2c;
+        sef.b2 = b.se.b2;
+        sef.np = se_ntiles * se_chunks;
+        sef.R = b.se.R;
+        sef.RP = se_padded_r(b.se.R);
+        sef.inv_hw = 1.0f / float(hw_out);
+    } else if (se_in_front) {
         // the front kernel already applied se_reduce to its channel sums (v.partial holds the
         // (tiles x chunks) partial vectors of every crop): finish the SEBlock
         SeExciteArgs a{};
@@ -506,7 +536,8 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.wp = b.project.wp;
         a.wdense = b.project.wdense;
         a.bias = b.project.bias;
-        a.gate = v.gate;
+        a.gate = se_fused ? nullptr : v.gate;
+        a.se = sef;
         a.res = sp.has_skip() ? in : nullptr;
         a.out = out;
         a.M = n * hw_out;
@@ -1191,6 +1222,7 @@ void Engine::op_block(int index, const float* in, int n, float* expand_out, floa
     float* d_f32 = static_cast<float*>(tmp.get(std::max({in_elems, exp_elems, dw_elems, out_elems}) * sizeof(float)));
     WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
     launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
+    WHENET_HIP_CHECK(hipMemsetAsync(gate_, 0xff, N * 1152 * sizeof(float), stream_));     // (NaN unless a launch writes it)
     enqueue_block(b, view(0), x0_, x1_, n, stream_, nullptr);
     auto fetch = [&](const void* src, size_t elems, float* dst) {
         if (!dst) return;

@@ -157,6 +157,8 @@ class Engine {
     int repeat_ = 1;
     bool split_heads_ = true;   // option "split_heads": GAP + Dense over 4 workgroups per crop, the last one decodes
     bool fuse_front_ = true;    // option "fuse_front": expand + depthwise as one kernel (front.hip / front2.hip)
+    int se_fuse_ = 1;           // option "se_fuse": the project GEMM computes the SE gate of its own crops in its prologue (no
+                                // squeeze-excite launch): 0 = never, 1 = on the blocks where that is faster, 2 = every fused-front block
     int front_impl_ = 1;        // option "front_impl": 0 = front.hip everywhere, 1 = per layer (f16: front2.hip where it is
                                 // the faster kernel), 2 = front2.hip everywhere (f16)
     int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")

@@ -84,6 +84,14 @@ int se_padded_r(int R);
 // 1x1 convolution as an MFMA GEMM over M = n*H*W rows:
 //   out[m][:] = act( (a[m][:] * gate[m / HW][:]) @ W + bias ) (+ res[m][:])
 enum { ACT_NONE = 0, ACT_SWISH = 1 };
+struct SeFuse {            // second half of a SEBlock computed by the project GEMM itself (se_device.h)
+    const float* rpart = nullptr;    // [n][np][RP] producer's squeeze-excite partial vectors, or nullptr (not fused)
+    const float* b1 = nullptr;       // [R]
+    const float* w2c = nullptr;      // [C][RP] excite kernel, channel-major, R zero-padded to RP
+    const float* b2 = nullptr;       // [C]
+    int np = 0, R = 0, RP = 0;
+    float inv_hw = 0.f;
+};
 struct PwArgs {
     const void* a;         // [M][K] T
     const void* wp;        // packed MFMA operand image (snapshot.h)
@@ -93,6 +101,7 @@ struct PwArgs {
     const void* res;       // [M][N] T or nullptr
     void* out;             // [M][N] T
     int M, K, N, KS, NTILES, HW, act;
+    SeFuse se;             // set: the kernel computes the gate of its rows' crops itself (gate must be nullptr)
 };
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream);
 

@@ -29,6 +29,7 @@
 // HBM bytes per launch: M*(K + N)*sizeof(T) (+ M*N*sizeof(T) skip) ; FLOPs 2*M*K*N.
 #include "device_math.h"
 #include "kernels.h"
+#include "se_device.h"
 
 namespace whenet {
 
@@ -51,10 +52,14 @@ namespace {
 //   * the combine is spread over the 4 waves: wave p owns a quarter of the accumulators (B2 = 2: one of
 //     the four tiles; B2 = 1: four consecutive out-channels), receives the other three waves' share of it
 //     through LDS and runs bias / skip / store for it.
-template <typename T, int B2, bool GATE, bool RES, int ACT>
+// GM: 0 = no gate, 1 = gate [n][K] from global memory (block 1, and every block with option se_fuse=0), 2 = the
+// workgroup computes the gate rows of its own crops from the producer's squeeze-excite partial vectors (se_device.h)
+template <typename T, int B2, int GM, bool RES, int ACT>
 __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     const T* __restrict__ A, const T* __restrict__ Wp, const float* __restrict__ bias, const T* __restrict__ gate,
-    const T* __restrict__ res, T* __restrict__ out, int M, int K, int N, int KS, int NTILES, int HW, int MT, int NCH) {
+    const T* __restrict__ res, T* __restrict__ out, int M, int K, int N, int KS, int NTILES, int HW, int MT, int NCH,
+    const SeFuse se) {
+    constexpr bool GATE = GM != 0;
     constexpr int V = Vec<T>::V;
     using VT = typename Vec<T>::type;
     using OT = T __attribute__((ext_vector_type(4)));
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     __shared__ float s_red[4 * 3 * SL * 64];        // [owner][source (3 others)][SL][lane]
     constexpr int GCROPS = MB + 1, GK = 1152;       // crops a workgroup's MB*32 rows can touch (HW >= 49), max K
     __shared__ __attribute__((aligned(16))) T s_gate[GATE ? GCROPS * GK : 8];
+    __shared__ float s_r[GM == 2 ? GCROPS * 48 : 4];
 
     const int id = blockIdx.x;
     const int q = id >> 3;
@@ -88,10 +94,10 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
         ap[mb] = A + size_t(rowc) * K + g * V;
         gp[mb] = GATE ? s_gate + (rowc / HW - crop_lo) * K + g * V : nullptr;
     }
-    if constexpr (GATE) {
+    const int row_last = (row_first + MB * 32 < M ? row_first + MB * 32 : M) - 1;
+    const int ncrop = row_last / HW - crop_lo + 1;                     // <= GCROPS
+    if constexpr (GM == 1) {
         // gate rows of crops crop_lo .. crop_hi -> LDS, 16 bytes per lane (K is a multiple of 16)
-        const int row_last = (row_first + MB * 32 < M ? row_first + MB * 32 : M) - 1;
-        const int ncrop = row_last / HW - crop_lo + 1;                 // <= GCROPS
         const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
         VT* dst = reinterpret_cast<VT*>(s_gate);
         for (int i = threadIdx.x; i < ncrop * K / V; i += 256) dst[i] = src[i];
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
 
     Ops o0, o1;
     issue(kpart, o0);
-    if constexpr (GATE) lds_barrier();              // the staged gate is complete (its global loads were issued first)
+    if constexpr (GM == 1) lds_barrier();           // the staged gate is complete (its global loads were issued first)
+    if constexpr (GM == 2) se_fused_to_lds<T, 256>(se, crop_lo, ncrop, K, s_gate, s_r);    // (operands already in flight)
     for (int ks = kpart; ks < KS; ks += 2 * U * SK) {
         issue(ks + U * SK, o1);
         compute(o0, ks);
@@ -230,13 +237,17 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
 //     lane stores 16 bytes and a wave-instruction writes whole 128-byte row segments of the
 //     NHWC output (the direct form scatters 8-byte pieces: the write path, not the MFMA, was
 //     what bounded the 6x-expanding layers).
-template <typename T, int NT, bool GATE, bool RES, int ACT>
+template <typename T, int NT, int GM, bool RES, int ACT>
 __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
                                                              const float* __restrict__ bias,
                                                              const T* __restrict__ gate,
                                                              const T* __restrict__ res, T* __restrict__ out, int M,
                                                              int K, int N, int KS, int NTILES, int HW, int MT,
-                                                             int NCH) {
+                                                             int NCH, const SeFuse se) {
+    constexpr bool GATE = GM != 0;
+    constexpr int TGK = 256;                                // K < 320 here: block 6's 240 is the widest gated layer
+    __shared__ __attribute__((aligned(16))) T s_gate[GM == 2 ? 2 * TGK : 8];     // 128 rows touch <= 2 crops (HW >= 196)
+    __shared__ float s_r[GM == 2 ? 2 * 12 : 4];
     constexpr int V = Vec<T>::V;
     using VT = typename Vec<T>::type;
     constexpr int UK = 4;                                   // k-steps per LDS stage (8: measured -3 % on the K = 32..96 layers)
@@ -269,7 +280,9 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
 
     const T* ap = A + size_t(rowc) * K + g * V;
     const T* gp = nullptr;
-    if constexpr (GATE) gp = gate + size_t(rowc / HW) * K + g * V;
+    const int crop_lo = (mt * 128) / HW;
+    if constexpr (GM == 1) gp = gate + size_t(rowc / HW) * K + g * V;
+    if constexpr (GM == 2) gp = s_gate + (rowc / HW - crop_lo) * K + g * V;        // (LDS)
     const VT* wsrc = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64;
 
     float16v acc[NT];
@@ -278,14 +291,17 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    auto load_a = [&](int ks) -> VT {
+    auto load_raw = [&](int ks) -> VT {
         VT a = vec_zero<T>();
-        if (rvalid && ks < KS && ks * 2 * V + g * V < K) {
-            a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
-            if constexpr (GATE) a = a * *reinterpret_cast<const VT*>(gp + ks * 2 * V);      // T x T, one rounding
-        }
+        if (rvalid && ks < KS && ks * 2 * V + g * V < K) a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
         return a;
     };
+    auto gated = [&](VT a, int ks) -> VT {
+        if constexpr (GATE)
+            if (rvalid && ks < KS && ks * 2 * V + g * V < K) a = a * *reinterpret_cast<const VT*>(gp + ks * 2 * V);   // T x T, one rounding
+        return a;
+    };
+    auto load_a = [&](int ks) -> VT { return gated(load_raw(ks), ks); };
 
     VT wreg[CPT];
     auto fetch_w = [&](int grp) {
@@ -311,7 +327,13 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     VT areg[UK];
     fetch_w(0);
 #pragma unroll
-    for (int u = 0; u < UK; ++u) areg[u] = load_a(u);
+    for (int u = 0; u < UK; ++u) areg[u] = load_raw(u);
+    if constexpr (GM == 2) {                                // the gate of this workgroup's <= 2 crops, while the first
+        const int row_last = (mt * 128 + 128 < M ? mt * 128 + 128 : M) - 1;        // operands travel
+        se_fused_to_lds<T, 256>(se, crop_lo, row_last / HW - crop_lo + 1, K, s_gate, s_r);
+    }
+#pragma unroll
+    for (int u = 0; u < UK; ++u) areg[u] = gated(areg[u], u);
     store_w(0);
     __syncthreads();
     for (int grp = 0; grp < G; ++grp) {
@@ -469,57 +491,61 @@ PwChoice choose_pw(const PwArgs& a, int num_cus) {
     return PwChoice{2, NT, ceil_div(a.NTILES, NT)};
 }
 
-template <typename T, int B2, bool GATE, bool RES, int ACT>
+template <typename T, int B2, int GM, bool RES, int ACT>
 void launch_splitk(const PwArgs& a, hipStream_t stream) {
     const int MT = ceil_div(a.M, 32 * B2), NCH = ceil_div(a.NTILES, B2);
-    hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GATE, RES, ACT>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
+    hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GM, RES, ACT>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
                        stream, static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias,
                        static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
-                       a.N, a.KS, a.NTILES, a.HW, MT, NCH);
+                       a.N, a.KS, a.NTILES, a.HW, MT, NCH, a.se);
 }
 
-template <typename T, int NT, bool GATE, bool RES, int ACT>
+template <typename T, int NT, int GM, bool RES, int ACT>
 void launch_tile(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
     const int blocks = 8 * ceil_div(MT, 8) * NCH;
-    hipLaunchKernelGGL((whenet_pw_tile_kernel<T, NT, GATE, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL((whenet_pw_tile_kernel<T, NT, GM, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
                        static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, static_cast<const T*>(a.gate),
                        static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES, a.HW, MT,
-                       NCH);
+                       NCH, a.se);
 }
 
-template <typename T, bool GATE, bool RES, int ACT>
+template <typename T, int GM, bool RES, int ACT>
 void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
     if (impl == 1) {
+        WHENET_REQUIRE(GM != 2, WHENET_EINVAL, "pointwise: the check kernel takes the gate from global memory (se_fuse=0)");
         const size_t work = size_t(a.M) * (a.N / 4);
-        hipLaunchKernelGGL((whenet_pw_check_kernel<T, GATE, RES, ACT>), dim3(unsigned((work + 255) / 256)), dim3(256),
+        hipLaunchKernelGGL((whenet_pw_check_kernel<T, GM != 0, RES, ACT>), dim3(unsigned((work + 255) / 256)), dim3(256),
                            0, stream, static_cast<const T*>(a.a), a.wdense, a.bias, static_cast<const T*>(a.gate),
                            static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.HW);
         return;
     }
     const PwChoice ch = choose_pw(a, num_cus);
     if (ch.kind == 1) {
-        if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, GATE, RES, ACT>(a, stream);
-        else launch_splitk<T, 1, GATE, RES, ACT>(a, stream);
+        if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, GM, RES, ACT>(a, stream);
+        else launch_splitk<T, 1, GM, RES, ACT>(a, stream);
         return;
     }
     const int MT = ceil_div(a.M, 128);
     switch (ch.NT) {
-        case 1: launch_tile<T, 1, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 2: launch_tile<T, 2, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 3: launch_tile<T, 3, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 4: launch_tile<T, 4, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 5: launch_tile<T, 5, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
-        default: launch_tile<T, 6, GATE, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 1: launch_tile<T, 1, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 2: launch_tile<T, 2, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 3: launch_tile<T, 3, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 4: launch_tile<T, 4, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 5: launch_tile<T, 5, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
+        default: launch_tile<T, 6, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
     }
 }
 
 template <typename T>
 void launch_dtype(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
-    const bool gate = a.gate != nullptr, res = a.res != nullptr;
-    // the network uses exactly three flavours: expand/head (swish), project (gate), project+skip
-    if (!gate && !res && a.act == ACT_SWISH) launch_variant<T, false, false, ACT_SWISH>(a, impl, num_cus, stream);
-    else if (gate && !res && a.act == ACT_NONE) launch_variant<T, true, false, ACT_NONE>(a, impl, num_cus, stream);
-    else if (gate && res && a.act == ACT_NONE) launch_variant<T, true, true, ACT_NONE>(a, impl, num_cus, stream);
+    const bool res = a.res != nullptr;
+    const int gm = a.se.rpart != nullptr ? 2 : (a.gate != nullptr ? 1 : 0);
+    // the network uses exactly these flavours: expand/head (swish), project (gate from memory | fused SE), + skip
+    if (gm == 0 && !res && a.act == ACT_SWISH) launch_variant<T, 0, false, ACT_SWISH>(a, impl, num_cus, stream);
+    else if (gm == 1 && !res && a.act == ACT_NONE) launch_variant<T, 1, false, ACT_NONE>(a, impl, num_cus, stream);
+    else if (gm == 1 && res && a.act == ACT_NONE) launch_variant<T, 1, true, ACT_NONE>(a, impl, num_cus, stream);
+    else if (gm == 2 && !res && a.act == ACT_NONE) launch_variant<T, 2, false, ACT_NONE>(a, impl, num_cus, stream);
+    else if (gm == 2 && res && a.act == ACT_NONE) launch_variant<T, 2, true, ACT_NONE>(a, impl, num_cus, stream);
     else throw Error(WHENET_EINVAL, "pointwise: unsupported epilogue combination");
 }
 
@@ -527,8 +553,13 @@ void launch_dtype(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
 
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream) {
     WHENET_REQUIRE(a.N % 4 == 0 && a.M > 0, WHENET_EINVAL, "pointwise: bad shape");
-    WHENET_REQUIRE(a.gate == nullptr || a.K < 320 || (a.K <= 1152 && a.K % 16 == 0 && a.HW >= 49), WHENET_EINVAL,
+    const bool gated = a.gate != nullptr || a.se.rpart != nullptr;
+    WHENET_REQUIRE(!(a.gate != nullptr && a.se.rpart != nullptr), WHENET_EINVAL, "pointwise: gate AND fused squeeze-excite");
+    WHENET_REQUIRE(!gated || a.K < 320 || (a.K <= 1152 && a.K % 16 == 0 && a.HW >= 49), WHENET_EINVAL,
                    "pointwise: gated deep contraction outside the staged-gate limits (K <= 1152, K % 16 == 0, HW >= 49)");
+    WHENET_REQUIRE(a.se.rpart == nullptr || (a.se.RP % 4 == 0 && a.se.RP <= 48 && a.se.np >= 1 &&
+                                             (a.K >= 320 || (a.K <= 256 && a.HW >= 196 && a.se.RP <= 12))),
+                   WHENET_EINVAL, "pointwise: fused squeeze-excite outside its limits");
     if (dtype == WHENET_F16) launch_dtype<half_t>(a, impl, num_cus, stream);
     else launch_dtype<float>(a, impl, num_cus, stream);
     WHENET_HIP_CHECK(hipGetLastError());
@@ -537,11 +568,11 @@ void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t st
 std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
     // the instantiation launch_pw() will pick, spelled as rocprofv3 prints it
     const char* t = dtype == WHENET_F16 ? "_Float16" : "float";
-    const char* gate = a.gate ? "true" : "false";
+    const char* gate = a.se.rpart ? "2" : (a.gate ? "1" : "0");
     const char* res = a.res ? "true" : "false";
     char buf[96];
     if (impl == 1) {
-        std::snprintf(buf, sizeof(buf), "whenet_pw_check_kernel<%s, %s, %s, %d>", t, gate, res, a.act);
+        std::snprintf(buf, sizeof(buf), "whenet_pw_check_kernel<%s, %s, %s, %d>", t, a.gate ? "true" : "false", res, a.act);
     } else {
         const PwChoice ch = choose_pw(a, num_cus);
         if (ch.kind == 1)

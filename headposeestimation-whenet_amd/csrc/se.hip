@@ -19,6 +19,7 @@
 // f32 throughout, fixed summation order (bitwise reproducible, independent of the batch).
 #include "device_math.h"
 #include "kernels.h"
+#include "se_device.h"
 #include "stamps.h"
 
 namespace whenet {
@@ -198,20 +199,8 @@ __global__ __launch_bounds__(256) void whenet_se_excite_kernel(const float* __re
         }
     }
     // r[j]: 4 running sums over the partial vectors p = u mod 4, combined (t0+t1)+(t2+t3)
-    if (tid < RP) {
-        const float* pp = rpart + size_t(b) * np * RP + tid;
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = 0; p < np; p += 16) {
-            float x[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = (p + u < np) ? pp[size_t(p + u) * RP] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (p + u < np) t[u & 3] += x[u];
-        }
-        const float r = ((t[0] + t[1]) + (t[2] + t[3])) * inv_hw;
-        s_r[tid] = (tid < R) ? swish_f<true>(r + b1[tid]) : 0.f;
-    }
+    if (tid < RP)          // (se_device.h: the arithmetic shared with the project GEMMs' fused prologue)
+        s_r[tid] = se_fused_r(rpart + size_t(b) * np * RP + tid, np, RP, inv_hw, tid < R ? b1[tid] : 0.f, tid < R);
     STAMP(1);
     lds_barrier();
     STAMP(2);

@@ -72,8 +72,15 @@ def test_info(handle):
     i = handle.info()
     assert i.abi_version == _lib.ABI_VERSION
     assert (i.params_backbone, i.params_heads, i.n_tensors) == (4_049_564, 322_812, 315)
-    # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads
-    assert i.macs_per_crop == spec.TOTAL_MACS and i.n_kernels_per_forward == 51
+    # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads = 51 with option se_fuse=0; by default the project
+    # GEMMs of the blocks where it pays compute their squeeze-excite gate themselves (f16: blocks 4-6; f32: by the same
+    # rule on front.hip's tile plans); 36 with se_fuse=2 (every block with a fused front kernel)
+    assert i.macs_per_crop == spec.TOTAL_MACS and 36 <= i.n_kernels_per_forward <= 50
+    handle.set_option("se_fuse", 0)
+    assert handle.info().n_kernels_per_forward == 51
+    handle.set_option("se_fuse", 2)
+    assert handle.info().n_kernels_per_forward == 36
+    handle.set_option("se_fuse", 1)
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
 
@@ -108,10 +115,17 @@ def test_mbconv_block_kernels(handle, taps, index):
     impls = (0, 2, 1) if (b.has_expand and handle.name == "f16") else (1,)
     for impl in impls:
         handle.set_option("front_impl", impl)
+        handle.set_option("se_fuse", 0)                    # (a squeeze-excite launch writes the gate: it can be checked)
         try:
             r = handle.op_block(index, x.astype(np.float32))
+            handle.set_option("se_fuse", 2)                # the project GEMM computes the gate itself (every block)
+            rf = handle.op_block(index, x.astype(np.float32))
         finally:
             handle.set_option("front_impl", 1)
+            handle.set_option("se_fuse", 1)
+        # the fused prologue's arithmetic is the stand-alone kernel's: the same block output, bit for bit
+        assert np.array_equal(rf["out"], r["out"]) and np.array_equal(rf["dw"], r["dw"]), f"se_fuse changes bits (front_impl={impl})"
+        assert not b.has_expand or np.isnan(rf["gate"]).all()          # (no launch wrote a gate)
         if b.has_expand:
             if impl == 0 or handle.name == "f32":
                 assert np.array_equal(r["dw"], r0["dw"]), "fused expand+depthwise differs from pw+dw"
@@ -526,6 +540,21 @@ def test_batch_8_and_batch_1(handle, weights, golden):
     for i in (0, 7):
         y1, a1, l1 = handle.forward(crops[i:i + 1])
         assert np.array_equal(l1[0], lg[i]) and np.array_equal(y1[0], ypr[i])
+
+
+def test_fused_squeeze_excite_is_bitwise_the_separate_launch(handle, golden):
+    """Option se_fuse (default on): blocks 2-16's project GEMMs compute the SE gate of their rows' crops in their
+    prologue (se_device.h) instead of reading the gate a squeeze-excite launch wrote.  Same arithmetic in the same order:
+    every logit is bitwise the 51-launch schedule's, for ragged batches over all lanes."""
+    crops = np.concatenate([golden["crops"], synth.scene_crops(45, seed=61)])          # 53 crops: 3 lanes of 17/18
+    y1, a1, l1 = handle.forward(crops)
+    try:
+        for mode in (0, 2):
+            handle.set_option("se_fuse", mode)
+            y0, a0, l0 = handle.forward(crops)
+            assert np.array_equal(l1, l0) and np.array_equal(y1, y0) and np.array_equal(a1, a0), mode
+    finally:
+        handle.set_option("se_fuse", 1)
 
 
 def test_front_impl_variants_end_to_end(blob, golden):
