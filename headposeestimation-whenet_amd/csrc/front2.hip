@@ -568,7 +568,7 @@ Front2Plan make_front2_plan(int k, int s, int Ho, int Cexp, int CC, int TH, int 
 }
 
 namespace {
-struct Tuned2 { int k, s, H, Cexp, CC, TH, TXG, xs, use; };
+struct Tuned2 { int k, s, H, Cexp, CC, TH, TXG, xs, use, threads; };
 const Tuned2 TUNED2[] = {
 #include "front2_tuned.inc"
 };
@@ -577,7 +577,7 @@ const Tuned2 TUNED2[] = {
 Front2Plan plan_front2(int k, int s, int H, int Ho, int Cexp) {
     if (!getenv("WHENET_FRONT_NO_TUNED"))
         for (const Tuned2& t : TUNED2)
-            if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp) return make_front2_plan(k, s, Ho, Cexp, t.CC, t.TH, t.TXG, 256, t.xs);
+            if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp) return make_front2_plan(k, s, Ho, Cexp, t.CC, t.TH, t.TXG, t.threads, t.xs);
     // shapes outside the table: 32 channels, 7 rows, the widest tile that leaves two workgroups per CU
     const int OXG = ceil_div(Ho, 4);
     for (int txg = OXG; txg >= 1; --txg)
@@ -613,15 +613,14 @@ std::vector<Front2Plan> plan_front2_candidates(int k, int s, int Ho, int Cexp) {
     return out;
 }
 
-// Lanes per workgroup for a launch of n crops.  Measured (tools/probes/front2_probe.hip, WHENET_FRONT_THREADS): 8-wave
-// workgroups are slower than 4-wave ones at 16 crops per launch on every layer (b4: 19.6 vs 13.7 us) and equal or
-// slower at 64 and 256, so the product launches 256 lanes; the 512-lane form stays for the probe (same bits: a wave's
-// share of tasks / items changes, not what a task or an item computes).
+// Lanes per workgroup for a launch of n crops: the plan's (front2_tuned.inc).  Measured (tools/probes/front2_probe.hip,
+// WHENET_FRONT_THREADS): 8-wave workgroups win only on block 2, whose 58 KB tile admits two workgroups per CU (216 vs
+// 228 us at 256 crops, 57.5 vs 59.2 at 64); everywhere else they are equal or slower (b4: 178 vs 118 us at 256 crops).
+// Same bits either way: a wave's share of tasks / items changes, not what a task or an item computes.
 int front2_threads(const Front2Plan& p, int n) {
     if (const char* e = getenv("WHENET_FRONT_THREADS")) return atoi(e);       // probes only
-    (void)p;
     (void)n;
-    return 256;
+    return p.threads;
 }
 
 void launch_front2(const Front2Args& a, hipStream_t stream) {
