@@ -311,7 +311,15 @@ def summarise_profile(stats, crops_per_launch):
                              "this, not HBM, is the binding roof of the fused expand+depthwise kernels (DESIGN.md 3)",
                      "swish_values_per_launch": dom["swish"] / dom["launches"],
                      "floor_us_per_launch": valu_floor_us / dom["launches"],
-                     "frac": (valu_floor_us / dom["us"]) if dom["us"] > 0 else None}}
+                     "frac": (valu_floor_us / dom["us"]) if (dom["us"] > 0 and dom["swish"] > 0) else None,
+                     "fused_front_kernels": None}}
+    # the same VALU roof for the class of kernels it binds: all fused expand+depthwise launches of the forward
+    fr = [k for k in by_kernel.values() if k["kind"] == "front"]
+    if fr:
+        fus, fsw = sum(k["us"] for k in fr), sum(k["swish"] for k in fr)
+        ffloor = fsw / 64.0 * SWISH_CYCLES_PER_WAVE_VALUE / SIMDS / (SHADER_GHZ * 1e3)
+        roof["valu"]["fused_front_kernels"] = {"launches": sum(k["launches"] for k in fr), "us": fus,
+                                                "swish_floor_us": ffloor, "frac": ffloor / fus if fus > 0 else None}
     return stats, by_kernel, dom_name, dom, roof, boundary_us
 
 
@@ -537,7 +545,9 @@ def main():
                 "chain_us_per_step": sum(st["raw_us"] for st in stats),
                 "by_kernel": {k: {"us": round(v["us"], 2), "launches": v["launches"],
                                   "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
-                                  "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2)}
+                                  "TFLOPs": round(v["flops"] / (v["us"] * 1e-6) / 1e12, 2),
+                                  "valu_frac": (round(v["swish"] / 64.0 * SWISH_CYCLES_PER_WAVE_VALUE / SIMDS /
+                                                      (SHADER_GHZ * 1e3) / v["us"], 3) if v["swish"] > 0 else None)}
                               for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["us"])}})
 
     out = {

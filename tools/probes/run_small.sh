@@ -1,1 +1,6 @@
-for s in b2 b3 b4 b5; do WHENET_FRONT_THREADS=512 ONLY=$s NOCHECK=1 timeout 100 ./tools/probes/front2_probe | grep -E "front2 def"; ONLY=$s NOCHECK=1 timeout 100 ./tools/probes/front2_probe | grep -E "front2 def"; done
+for M in 2 3 4; do python bench.py --inflight $M --no-cpu-baseline --no-latency --no-sweep --steps 200 --warmup 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('inflight', d['config']['forwards_in_flight'], round(d['value']), round(d['value_serial'] or 0))"; done
+for B in 128 256; do python bench.py --batch $B --no-cpu-baseline --no-latency --no-sweep --steps 100 --warmup 10 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch', d['config']['batch_per_gpu'], round(d['value']), round(d['value_serial'] or 0))"; done
