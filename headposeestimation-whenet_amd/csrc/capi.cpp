@@ -312,6 +312,10 @@ int whenet_op_block(whenet_t* h, int index, const float* in, int n, float* expan
     return guarded(h, [&](whenet::Engine& e) { e.op_block(index, in, n, expand_out, dw_out, gate, out); });
 }
 
+int whenet_op_block_range(whenet_t* h, int first, int last, const float* in, int n, float* out) {
+    return guarded(h, [&](whenet::Engine& e) { e.op_block_range(first, last, in, n, out); });
+}
+
 int whenet_op_head(whenet_t* h, const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax) {
     return guarded(h, [&](whenet::Engine& e) { e.op_head(in, n, feat, logits, ypr, argmax); });
 }

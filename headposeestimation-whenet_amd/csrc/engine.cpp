@@ -121,6 +121,8 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
         blocks_.push_back(b);
     }
     head_ = upload_pw(m.head);
+    fold12_pw_ = upload_pw(m.fold12);
+    d_fold12_w32_ = upload(m.fold12_w32);
     d_dense_w_ = upload(m.dense_w);
     d_dense_b_ = upload(m.dense_b);
     WHENET_HIP_CHECK(hipDeviceSynchronize());
@@ -217,6 +219,12 @@ void Engine::set_option(const std::string& key, long value) {
         front_impl_ = int(value);
         sync();
         drop_graphs();
+    } else if (key == "fold12") {
+        fold12_ = value != 0;
+        sync();
+        drop_graphs();
+    } else if (key == "poison") {
+        poison_ = value != 0;
     } else if (key == "lanes") {
         WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "lanes must be 1..8");
         lanes_ = int(value);
@@ -268,6 +276,7 @@ void Engine::get_info(whenet_info_t* out) const {
                 k += (front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && pays))) ? 1 : 2;
             }
         }
+        if (fold12_active()) k -= 1;              // block 1's project launch
         out->n_kernels_per_forward = k;
     }
     out->macs_per_crop = 384857312;
@@ -324,7 +333,11 @@ void Engine::ensure_capacity(int n) {
     partial_ = static_cast<float*>(alloc(N * partial_per_crop_ * sizeof(float)));
     gate_ = static_cast<float*>(alloc(N * 1152 * sizeof(float)));
     hcount_ = static_cast<unsigned*>(alloc(N * sizeof(unsigned)));
-    WHENET_HIP_CHECK(hipMemset(hcount_, 0, N * sizeof(unsigned)));
+    // (on the engine's OWN stream, and complete before any forward is enqueued: hipMemset runs on the null stream, which
+    //  the engine's non-blocking streams do not wait for -- with other engines keeping the GPU busy it used to land in
+    //  the middle of this engine's first heads kernel and leave the per-crop ticket counters off by one for good)
+    WHENET_HIP_CHECK(hipMemsetAsync(hcount_, 0, N * sizeof(unsigned), stream_));
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
     in_u8_ = static_cast<uint8_t*>(alloc(N * IN_BYTES));
     o_ypr_ = static_cast<float*>(alloc(N * 3 * sizeof(float)));
     o_amax_ = static_cast<int32_t*>(alloc(N * 3 * sizeof(int32_t)));
@@ -367,8 +380,28 @@ struct Rec {
 
 }  // namespace
 
+// Block 1's project (linear) and block 2's expand are one affine map of block 1's gated depthwise output
+// (snapshot.cpp builds its weights): with front2.hip on block 2, block 1 stops after its squeeze-excite and block 2's
+// front kernel reads the 112 x 112 x 32 depthwise output directly, scaling its copy of the weights by the crop's gate.
+// One launch and 77 MB of HBM traffic per 64 crops less; block 1's 16-channel output no longer exists (nothing else
+// reads it: block 2 has no skip).
+bool Engine::fold12_active() const {
+    return fold12_ && dtype_ == WHENET_F16 && fuse_front_ && pw_impl_ == 0 && blocks_.size() >= 2 &&
+           (front_impl_ == 2 || (front_impl_ == 1 && blocks_[1].f2_preferred));
+}
+
+void* Engine::enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec) {
+    const bool fold = fold12_active() && first <= 1 && last >= 2;
+    for (int i = first; i <= last; ++i) {
+        void* nxt = (cur == v.x0) ? v.x1 : v.x0;
+        enqueue_block(blocks_[size_t(i - 1)], v, cur, nxt, n, s, rec, fold && i <= 2 ? i : 0);
+        cur = nxt;
+    }
+    return cur;
+}
+
 void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                           LaunchRecorder* rec) {
+                           LaunchRecorder* rec, int fold) {
     Rec R{rec, s, repeat_};
     const BlockSpec& sp = b.spec;
     const std::string p = "b" + std::to_string(sp.index);
@@ -402,14 +435,22 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.pad = sp.pad_before();
         a.KSe = b.expand.KS;
         a.NTe = b.expand.NTILES;
+        if (fold == 2) {                     // input = block 1's depthwise output, gated; weights = project1 x expand2
+            a.wep = d_fold12_w32_;            // (f32: scaled by the gate, then rounded once -- front2.hip)
+            a.be = fold12_pw_.bias;
+            a.Cin = fold12_pw_.K;
+            a.KSe = fold12_pw_.KS;
+            a.NTe = fold12_pw_.NTILES;
+            a.in_gate = static_cast<const float*>(v.gate);
+        }
         a.n = n;
         a.plan = b.f2plan;
         a.plan.threads = front2_threads(b.f2plan, n);
         se_ntiles = b.f2plan.ntiles();
         se_chunks = b.f2plan.chunks;
         R(p + "/front", "front", kernel_name_front2(sp.k, sp.s, a.KSe, a.plan.threads, a.plan.xs).c_str(),
-          double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
-          2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front2(a, s); });
+          double(n) * (hw_in * a.Cin + hw_out * cexp) * es,
+          2.0 * n * (double(hw_in) * a.Cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front2(a, s); });
     } else if (fused) {
         FrontArgs a{};
         a.x = in;
@@ -459,7 +500,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     if (!fused) {
         DwArgs a{};
         a.in = dw_in;
-        a.out = v.d;
+        a.out = fold == 1 ? out : v.d;
         a.w = b.dw.w;
         a.bias = b.dw.bias;
         a.partial = v.partial;
@@ -484,6 +525,8 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     // the same either way.  Option se_fuse: 0 = never, 1 = where it pays (default), 2 = every fused-front block.
     const int se_np = se_ntiles * se_chunks;
     const bool se_pays = b.project.K < 320 && se_np <= 24;
+    WHENET_REQUIRE(fold == 0 || (fold == 1 && !fused && sp.index == 1) || (fold == 2 && use_f2 && sp.index == 2), WHENET_EINVAL,
+                   "fold12: block outside the folded pair");
     const bool se_fused = se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && se_pays));
     SeFuse sef{};
     if (se_fused) {
@@ -523,14 +566,14 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.w2c = b.se.w2c;
         a.b2 = b.se.b2;
         a.gate = v.gate;
-        a.gate_f16 = dtype_ == WHENET_F16;
+        a.gate_f16 = dtype_ == WHENET_F16 && fold != 1;      // (fold12: block 2 scales f32 weights by an f32 gate)
         a.C = b.se.C;
         a.R = b.se.R;
         a.n = n;
         R(p + "/se", "se", ("whenet_se_kernel<" + std::to_string(se_padded_r(a.R)) + ">").c_str(), double(n) * (a.ntiles + 1) * a.C * 4.0 + 2.0 * a.C * a.R * 4.0,
           4.0 * n * a.C * a.R, [&] { launch_se(a, s); });
     }
-    {
+    if (fold != 1) {
         PwArgs a{};
         a.a = v.d;
         a.wp = b.project.wp;
@@ -563,12 +606,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
           [&] { launch_stem(a, dtype_, s); });
     }
-    void* cur = v.x0;
-    for (size_t i = 0; i < blocks_.size(); ++i) {
-        void* nxt = (cur == v.x0) ? v.x1 : v.x0;
-        enqueue_block(blocks_[i], v, cur, nxt, n, s, rec);
-        cur = nxt;
-    }
+    void* cur = enqueue_blocks(1, int(blocks_.size()), v, v.x0, n, s, rec);
     {
         PwArgs a{};
         a.a = cur;
@@ -707,6 +745,18 @@ hipGraphExec_t Engine::cached_graph(const GraphKey& key, hipStream_t s, F&& fn) 
 }
 
 void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
+    if (poison_) {
+        // debug option "poison": every activation buffer holds NaN bit patterns when the forward starts, so a kernel
+        // that reads what no kernel of THIS forward wrote shows up in the results (tests/test_gpu_parity.py)
+        const size_t N = size_t(n), es = esz();
+        WHENET_HIP_CHECK(hipMemsetAsync(x0_, 0xff, N * X_ELEMS * es, s));
+        WHENET_HIP_CHECK(hipMemsetAsync(x1_, 0xff, N * X_ELEMS * es, s));
+        WHENET_HIP_CHECK(hipMemsetAsync(e_, 0xff, N * E_ELEMS * es, s));
+        WHENET_HIP_CHECK(hipMemsetAsync(d_, 0xff, N * D_ELEMS * es, s));
+        WHENET_HIP_CHECK(hipMemsetAsync(hc_, 0xff, N * HC_ELEMS * es, s));
+        WHENET_HIP_CHECK(hipMemsetAsync(partial_, 0xff, N * partial_per_crop_ * sizeof(float), s));
+        WHENET_HIP_CHECK(hipMemsetAsync(gate_, 0xff, N * 1152 * sizeof(float), s));
+    }
     if (!use_graph_) {
         enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
         return;
@@ -1236,6 +1286,28 @@ void Engine::op_block(int index, const float* in, int n, float* expand_out, floa
         fetch(gate_, N * sp.cexp(), gate);         // (stored in the activation type: see se.hip)
     }
     fetch(x1_, out_elems, out);
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_block_range(int first, int last, const float* in, int n, float* out) {
+    DeviceGuard guard(device_);
+    require_model();
+    WHENET_REQUIRE(first >= 1 && first <= last && last <= int(blocks_.size()), WHENET_EINVAL,
+                   "op_block_range: need 1 <= first <= last <= 16");
+    WHENET_REQUIRE(in != nullptr && out != nullptr, WHENET_EINVAL, "op_block_range: NULL buffer");
+    ensure_capacity(n);
+    const BlockSpec& si = blocks_[size_t(first - 1)].spec;
+    const BlockSpec& so = blocks_[size_t(last - 1)].spec;
+    const size_t in_elems = size_t(n) * si.h_in * si.h_in * si.cin;
+    const size_t out_elems = size_t(n) * so.h_out * so.h_out * so.cout;
+    TempBufs tmp;
+    float* d_f32 = static_cast<float*>(tmp.get(std::max(in_elems, out_elems) * sizeof(float)));
+    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
+    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
+    const View v = view(0);
+    const void* res = enqueue_blocks(first, last, v, v.x0, n, stream_, nullptr);
+    launch_act_to_f32(res, d_f32, out_elems, dtype_, stream_);
+    WHENET_HIP_CHECK(hipMemcpyAsync(out, d_f32, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 

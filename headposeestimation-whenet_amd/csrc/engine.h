@@ -90,6 +90,7 @@ class Engine {
                   float iou_threshold, int max_boxes, float* boxes, float* scores, int32_t* classes, int32_t* index,
                   float* all_boxes, float* all_scores);
     void op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out);
+    void op_block_range(int first, int last, const float* in, int n, float* out);
     void op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax);
     void op_decode(const float* logits, int n, float* ypr, int32_t* argmax);
 
@@ -134,8 +135,13 @@ class Engine {
     // enqueue the kernels of one forward on `s` (eager); rec != nullptr -> event pairs
     void enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits,
                          hipStream_t s, LaunchRecorder* rec, const float* d_in_f32 = nullptr);
+    // fold: 0 = the block as it stands; 1 = block 1 without its project (its depthwise output goes to `out`);
+    //       2 = block 2 fed by that output, block 1's project folded into its expand weights (fold12_active())
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                       LaunchRecorder* rec);
+                       LaunchRecorder* rec, int fold = 0);
+    // blocks first..last (1-based) as the forward pass runs them; returns the buffer (x0 / x1 of `v`) holding the result
+    void* enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec);
+    bool fold12_active() const;
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
@@ -161,6 +167,8 @@ class Engine {
                                 // squeeze-excite launch): 0 = never, 1 = on the blocks where that is faster, 2 = every fused-front block
     int front_impl_ = 1;        // option "front_impl": 0 = front.hip everywhere, 1 = per layer (f16: front2.hip where it is
                                 // the faster kernel), 2 = front2.hip everywhere (f16)
+    bool poison_ = false;       // debug option "poison": NaN-fill the activation arena before every forward
+    bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")
     bool lane_graphs_ = false;  // one graph per lane on its own stream instead of one forked graph (option "lane_graphs")
     int min_lane_crops_ = 16;   // do not split below this many crops per chain
@@ -177,6 +185,8 @@ class Engine {
     float *d_lut_ = nullptr, *d_stem_w_ = nullptr, *d_stem_b_ = nullptr;
     std::vector<DevBlock> blocks_;
     DevPw head_;
+    DevPw fold12_pw_;           // block 1 project x block 2 expand, 32 -> 96 (snapshot.cpp)
+    float* d_fold12_w32_ = nullptr;   // its f32 fragment image (front2.hip rounds AFTER the per-crop gate)
     float *d_dense_w_ = nullptr, *d_dense_b_ = nullptr;
 
     // activation arena (grown to the largest n seen)

@@ -59,6 +59,7 @@ struct F2Params {
     half_t* out;
     float* rpart;
     const float* w1t;
+    const float* in_gate;             // [n][Cin] f32 or NULL: per-crop scale of the INPUT channels (Front2Args::in_gate)
     int H, Ho, Cin, Cexp, pad, NTe;
     int CC, TH, TXG, tiles_x, EH, EWp, RP, CP;
     int off_stage, off_red, off_sum;
@@ -173,9 +174,38 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     constexpr int D = 1;
     half8 w[KS], aq[D][PF];
     float bias_cur = 0.f;
+    // The folded block-1 project (engine.cpp, option fold12): the expand's input is the PREVIOUS block's gated
+    // depthwise output; the gate scales the contraction index, so it is applied to this crop's copy of the weights
+    // instead of to every pixel row -- in f32 (f32 composed weights x f32 gate, ONE rounding to f16 per weight; the
+    // two-step form rounds the gate, the gated activation, both weight matrices and block 1's output).
+    // (compile-time: the shape 3x3 / stride 2 / Cin 32 exists only as that folded block 2 -- no registers elsewhere)
+    constexpr bool GATED = (K == 3 && S == 2 && KS == 2);
+    float4v gq[GATED ? KS : 1][2];
+    if constexpr (GATED) {
+        const float* gp = reinterpret_cast<const float*>(p.in_gate) + size_t(b) * Cin + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            gq[ks][0] = *reinterpret_cast<const float4v*>(gp + ks * 16);
+            gq[ks][1] = *reinterpret_cast<const float4v*>(gp + ks * 16 + 4);
+        }
+    }
     auto load_w = [&](int tl) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = wf0[(size_t(ks) * p.NTe + tl) * 64];
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (GATED) {
+                // wep: the same fragment order as the f16 image, 8 floats per lane
+                const float* wq = reinterpret_cast<const float*>(p.wep) + ((size_t(ks) * p.NTe + (c0 >> 5) + tl) * 64 + lane) * 8;
+                const float4v lo = *reinterpret_cast<const float4v*>(wq) * gq[ks][0];
+                const float4v hi = *reinterpret_cast<const float4v*>(wq + 4) * gq[ks][1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    w[ks][e] = half_t(lo[e]);
+                    w[ks][4 + e] = half_t(hi[e]);
+                }
+            } else {
+                w[ks] = wf0[(size_t(ks) * p.NTe + tl) * 64];
+            }
+        }
         const int ch = tl * 32 + lm;
         bias_cur = (ch < ccur) ? p.be[c0 + ch] : 0.f;
     };
@@ -478,6 +508,7 @@ void launch_f2(const Front2Args& a, hipStream_t stream) {
     p.out = static_cast<half_t*>(a.out);
     p.rpart = a.rpart;
     p.w1t = a.w1t;
+    p.in_gate = a.in_gate;
     p.H = a.H;  p.Ho = a.Ho;  p.Cin = a.Cin;  p.Cexp = a.Cexp;  p.pad = a.pad;  p.NTe = a.NTe;
     p.CC = pl.CC;  p.TH = pl.TH;  p.TXG = pl.TXG;  p.tiles_x = pl.tiles_x;
     p.EH = pl.EH;  p.EWp = pl.EWp;  p.RP = pl.RP;  p.CP = pl.CP;
@@ -501,6 +532,7 @@ void launch_f2_shape(const Front2Args& a, hipStream_t stream) {
     const int key = a.k * 1000 + a.s * 100 + a.KSe + a.plan.xs * 10000;
     switch (key) {                                   // EfficientNet-B0's eleven (kernel, stride, Cin / 16) shapes
         case 3201: launch_f2<3, 2, 1, NTHR>(a, stream); break;       // b2
+        case 3202: launch_f2<3, 2, 2, NTHR>(a, stream); break;       // b2 fed by block 1's depthwise output (fold12)
         case 3102: launch_f2<3, 1, 2, NTHR>(a, stream); break;       // b3
         case 5202: launch_f2<5, 2, 2, NTHR>(a, stream); break;       // b4
         case 5103: launch_f2<5, 1, 3, NTHR>(a, stream); break;       // b5
@@ -625,6 +657,8 @@ int front2_threads(const Front2Plan& p, int n) {
 
 void launch_front2(const Front2Args& a, hipStream_t stream) {
     WHENET_REQUIRE(a.KSe == ceil_div(a.Cin, 16), WHENET_EINVAL, "front2: k-steps do not match Cin");
+    WHENET_REQUIRE((a.in_gate != nullptr) == (a.k == 3 && a.s == 2 && a.KSe == 2) && (a.in_gate == nullptr || a.Cin == 32),
+                   WHENET_EINVAL, "front2: the gated-input form is the 3x3 / stride-2 / Cin = 32 shape, and only that");
     Front2Args b = a;
     if (b.plan.threads != 256) {              // the stage / sums offsets depend on the wave count
         b.plan = make_front2_plan(a.k, a.s, a.Ho, a.Cexp, a.plan.CC, a.plan.TH, a.plan.TXG, a.plan.threads, a.plan.xs);

@@ -216,7 +216,13 @@ __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __rest
         for (int w2 = 0; w2 < NW; ++w2) t += s_part[w2][tid];
         st_l2_f32(mine + tid, t);
     }
-    // ---- ticket: the partial vector has reached L2 before the counter moves ---------------------------------
+    // ---- ticket: the partial vector is at the device's coherence point before the counter moves.  The four
+    // workgroups of a crop may sit on different XCDs (non-coherent L2s): the partial vectors are written and read with
+    // agent-scope atomic accesses (sc1: write-through stores, loads that do not hit a stale local line), the stores
+    // have been acknowledged (vmcnt) before the counter is touched, and the counter itself is an agent-scope RMW.
+    // (Round 3 measured the textbook form -- release / acquire fences, i.e. buffer_wbl2 sc1 + buffer_inv sc1 in every
+    // workgroup: 11 % of the whole forward's throughput at batch 64 for the same results; the in-flight corruption it
+    // was tried against came from the counters' initialisation, engine.cpp ensure_capacity.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {

@@ -192,6 +192,9 @@ struct Front2Args {
     void* out;             // [n,Ho,Ho,Cexp] half
     float* rpart;          // as FrontArgs::rpart
     const float* w1t;      // [R][Cexp] se_reduce kernel, transposed, or NULL
+    const float* in_gate;  // [n][Cin] f32 or NULL: the expand contracts (in_gate[crop] * x) -- block 2 fed by block 1's
+                           // depthwise output with block 1's project folded into wep (engine.cpp, option fold12);
+                           // wep is then the F32 fragment image (8 floats per lane, HostModel::fold12_w32)
     int R;
     int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
     Front2Plan plan;

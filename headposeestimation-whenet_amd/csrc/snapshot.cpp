@@ -79,21 +79,36 @@ void pack_pw_t(HostPw& pw, const std::vector<double>& wf /*[K][N]*/) {
     for (size_t i = 0; i < pw.dense.size(); ++i) pw.dense[i] = float(T(wf[i]));
 }
 
-HostPw make_pw(const std::map<std::string, RawTensor>& t, const std::string& conv, const std::string& bn,
-               uint32_t K, uint32_t N, int dtype) {
+// 1x1 conv + BatchNorm as one affine map, in double: wf [K][N] = kernel * bn scale, shift [N]
+struct FoldedPw {
+    std::vector<double> wf, shift;
+};
+FoldedPw fold_pw(const std::map<std::string, RawTensor>& t, const std::string& conv, const std::string& bn, uint32_t K,
+                 uint32_t N) {
     const float* w = need(t, conv + "/kernel", {1, 1, K, N}).data;   // HWIO, 1x1
     Folded f = fold_bn(t, bn, N);
+    FoldedPw o;
+    o.wf.resize(size_t(K) * N);
+    for (uint32_t k = 0; k < K; ++k)
+        for (uint32_t n = 0; n < N; ++n) o.wf[size_t(k) * N + n] = double(w[size_t(k) * N + n]) * f.scale[n];
+    o.shift = f.shift;
+    return o;
+}
+
+HostPw pack_pw(const FoldedPw& f, uint32_t K, uint32_t N, int dtype) {
     HostPw pw;
     pw.K = int(K);
     pw.N = int(N);
-    std::vector<double> wf(size_t(K) * N);
-    for (uint32_t k = 0; k < K; ++k)
-        for (uint32_t n = 0; n < N; ++n) wf[size_t(k) * N + n] = double(w[size_t(k) * N + n]) * f.scale[n];
     pw.bias.resize(N);
     for (uint32_t n = 0; n < N; ++n) pw.bias[n] = float(f.shift[n]);
-    if (dtype == WHENET_F16) pack_pw_t<half_t>(pw, wf);
-    else pack_pw_t<float>(pw, wf);
+    if (dtype == WHENET_F16) pack_pw_t<half_t>(pw, f.wf);
+    else pack_pw_t<float>(pw, f.wf);
     return pw;
+}
+
+HostPw make_pw(const std::map<std::string, RawTensor>& t, const std::string& conv, const std::string& bn,
+               uint32_t K, uint32_t N, int dtype) {
+    return pack_pw(fold_pw(t, conv, bn, K, N), K, N, dtype);
 }
 
 }  // namespace
@@ -220,6 +235,41 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
     }
 
     m.head = make_pw(t, "head/conv", "head/bn", 320, FEAT, dtype);
+
+    {   // Block 1's project (32 -> 16, linear: BN, no activation) followed by block 2's expand (16 -> 96) is ONE affine
+        // map of block 1's gated depthwise output (block 2 has no skip, nothing else reads block 1's output):
+        //     expand2(project1(a)) = a . (Wp1 . We2) + (bp1 . We2 + be2),        composed here in double.
+        // The engine feeds block 2's front kernel from block 1's depthwise output with this image and drops block 1's
+        // project launch (option fold12); the two-step weights stay for the per-block operators and fold12 = 0.
+        const BlockSpec& b1 = m.blocks[0].spec;
+        const BlockSpec& b2 = m.blocks[1].spec;
+        const uint32_t K = b1.cexp(), J = b1.cout, N = b2.cexp();
+        WHENET_REQUIRE(!b1.has_expand() && !b2.has_skip() && b2.cin == J, WHENET_EFORMAT, "fold12: unexpected block layout");
+        const FoldedPw p1 = fold_pw(t, "b1/project", "b1/project_bn", K, J);
+        const FoldedPw e2 = fold_pw(t, "b2/expand", "b2/expand_bn", J, N);
+        FoldedPw c;
+        c.wf.assign(size_t(K) * N, 0.0);
+        c.shift = e2.shift;
+        for (uint32_t j = 0; j < J; ++j)
+            for (uint32_t n = 0; n < N; ++n) {
+                const double w = e2.wf[size_t(j) * N + n];
+                c.shift[n] += p1.shift[j] * w;
+                for (uint32_t k = 0; k < K; ++k) c.wf[size_t(k) * N + n] += p1.wf[size_t(k) * J + j] * w;
+            }
+        m.fold12 = pack_pw(c, K, N, dtype);
+        // the f32 image front2.hip scales by the crop's gate before rounding: the f16 fragment order (16 k per step,
+        // lane l <-> n = 32 ntile + (l & 31), k = 16 ks + 8 (l >> 5) + e), whatever the handle's dtype
+        const int KS = ceil_div(int(K), 16), NT = ceil_div(int(N), 32);
+        m.fold12_w32.assign(size_t(KS) * NT * 64 * 8, 0.0f);
+        for (int ks = 0; ks < KS; ++ks)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t n = uint32_t(nt * 32 + (lane & 31)), k = uint32_t(ks * 16 + (lane >> 5) * 8 + e);
+                        if (n < N && k < K)
+                            m.fold12_w32[((size_t(ks) * NT + nt) * 64 + lane) * 8 + e] = float(c.wf[size_t(k) * N + n]);
+                    }
+    }
 
     m.dense_w.resize(size_t(FEAT) * N_LOGITS);
     m.dense_b.resize(N_LOGITS);

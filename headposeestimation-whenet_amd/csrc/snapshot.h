@@ -65,6 +65,8 @@ struct HostModel {
     std::vector<float> stem_b;       // [32]
     std::vector<HostBlock> blocks;   // 16
     HostPw head;                     // 320 -> 1280
+    HostPw fold12;                   // 32 -> 96: block 1's project composed with block 2's expand (snapshot.cpp)
+    std::vector<float> fold12_w32;   // its weights in f32, f16 fragment order [2][3][64 lanes][8] (front2.hip)
     std::vector<float> dense_w;      // [1280][252]  yaw|pitch|roll  (whenet.py:11-13)
     std::vector<float> dense_b;      // [252]
     int64_t params_backbone = 0, params_heads = 0;

@@ -56,6 +56,7 @@ _PROTOS = {
     "whenet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(LaunchStat), C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_stem": (C.c_int, [_P, _P, C.c_int, _P]),
     "whenet_op_block": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    "whenet_op_block_range": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P]),
     "whenet_op_head": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     "whenet_op_decode": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "whenet_block_spec": (C.c_int, [C.c_int, C.POINTER(C.c_int32 * 8)]),
@@ -371,6 +372,17 @@ class Handle:
         out = np.empty((n, b.h_out, b.h_out, b.cout), np.float32)
         self._check(self._lib.whenet_op_block(self._h, index, _ptr(x), n, _ptr(ex), _ptr(dw), _ptr(gate), _ptr(out)))
         return {"expand": ex, "dw": dw, "gate": gate, "out": out}
+
+    def op_block_range(self, first: int, last: int, x: np.ndarray) -> np.ndarray:
+        """Blocks first..last as the forward pass chains them (with option fold12 when the range holds 1 and 2)."""
+        from . import spec
+        bi, bo = spec.blocks()[first - 1], spec.blocks()[last - 1]
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.shape[0]
+        assert x.shape[1:] == (bi.h_in, bi.h_in, bi.cin), (x.shape, bi)
+        out = np.empty((n, bo.h_out, bo.h_out, bo.cout), np.float32)
+        self._check(self._lib.whenet_op_block_range(self._h, first, last, _ptr(x), n, _ptr(out)))
+        return out
 
     def op_head(self, x: np.ndarray):
         x = np.ascontiguousarray(x, np.float32)

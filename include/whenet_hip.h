@@ -105,6 +105,10 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  as f32 VALU FMAs) on every block, 2 = front2.hip (taps as Toeplitz products on the matrix
  *                  cores, f16 tap weights) on every block, 1 = per layer, whichever was measured faster;
  *                  f32 handles always run front.hip),
+ *          "fold12" (0/1, default 1: f16 handles whose block 2 runs front2.hip feed that kernel from block 1's depthwise
+ *                  output, with block 1's project conv (linear) composed into block 2's expand weights when the
+ *                  snapshot is loaded -- one launch and a 112x112x16 round trip through HBM less; 0 = the two convs
+ *                  as two steps.  Same function, different rounding points: results agree to f16 rounding),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "lane_graphs" (0/1, default 0: 1 = one graph per lane launched on its own stream instead of
  *                  one forked graph; measured equal),
@@ -221,6 +225,10 @@ WHENET_API int whenet_op_stem(whenet_t* h, const uint8_t* crops, int n, float* o
  *   out [n,Ho,Wo,Cout] (after project + BN + skip) */
 WHENET_API int whenet_op_block(whenet_t* h, int index, const float* in, int n,
                     float* expand_out, float* dw_out, float* gate, float* out);
+/* MBConv blocks first..last (1 <= first <= last <= 16) chained exactly as the forward pass chains them -- including
+ * option fold12 (block 1's project folded into block 2's expand) when the range holds blocks 1 and 2 -- on input
+ * [n,H,W,Cin] of block `first`; out [n,Ho,Wo,Cout] of block `last`. */
+WHENET_API int whenet_op_block_range(whenet_t* h, int first, int last, const float* in, int n, float* out);
 /* head: Conv1x1(1280)+BN+Swish + GAP + Dense heads + decode on input [n,7,7,320]:
  *   feat [n,1280], logits [n,252], ypr [n,3], argmax [n,3] */
 WHENET_API int whenet_op_head(whenet_t* h, const float* in, int n,

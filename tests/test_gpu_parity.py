@@ -5,9 +5,14 @@ Tolerances (stated here, per dtype):
   f32  angles <= 1e-3 deg (the north-star bar), bin argmax equal wherever the oracle's top-2
        logit margin exceeds 2e-3 (float32 round-off moves logits by ~3e-4, see
        tests/golden/golden.json noise_floor_*), per-kernel tensors <= 2e-5 * scale;
-  f16  cannot meet 1e-3 deg (10-bit mantissa through 82 conv layers): angles <= F16_DEG (0.5;
-       0.05-0.27 measured), per-kernel tensors <= 1.5e-2 * scale (each kernel alone, fed oracle inputs
-       rounded to f16); bin argmax: asserted on EVERY golden crop -- equal, or the oracle's top-2
+  f16  cannot meet 1e-3 deg (10-bit mantissa through 82 conv layers).  Its error is rounding NOISE with a long tail:
+       over 1536 angles (512 crops) mean 0.048, p95 0.21, p99 0.47, max 1.2 deg, and WHICH angle is the outlier
+       changes with every change of a rounding point (round 2's own error study, profiles/r02/f16_error_study.txt,
+       has maxima from 0.42 to 0.90 deg on the same 48 crops across rounding subsets).  So the contract is stated on
+       the distribution (test_f16_accuracy_contract, test_f16_error_distribution_512_crops: mean / p95 / p99 / bin
+       flips), and every single angle checked anywhere is within F16_DEG = 1.5 deg = half a 3-degree bin;
+       per-kernel tensors <= 1.5e-2 * scale (each kernel alone, fed oracle inputs rounded to f16);
+       bin argmax: asserted on EVERY golden crop -- equal, or the oracle's top-2
        margin is below the measured logit error (the synthetic heads are 3-bin-wide Gaussian bumps:
        neighbouring bins differ by <= 0.38, so f16 may legitimately pick the neighbour) and the
        picked bin is the oracle's runner-up; at most F16_ARGMAX_FLIPS of the 24 may flip.
@@ -23,7 +28,7 @@ from whenet_hip import _lib, spec, synth, weights as W
 pytestmark = pytest.mark.gpu
 
 F32_DEG = 1e-3
-F16_DEG = 0.5
+F16_DEG = 1.5
 F16_ARGMAX_FLIPS = 3
 MARGIN_F32 = 2e-3
 DTYPES = [("f32", _lib.F32), ("f16", _lib.F16)]
@@ -75,12 +80,19 @@ def test_info(handle):
     # stem, dw(b1), 15 front, 16 se, 16 project, head conv, heads = 51 with option se_fuse=0; by default the project
     # GEMMs of the blocks where it pays compute their squeeze-excite gate themselves (f16: blocks 4-6; f32: by the same
     # rule on front.hip's tile plans); 36 with se_fuse=2 (every block with a fused front kernel)
-    assert i.macs_per_crop == spec.TOTAL_MACS and 36 <= i.n_kernels_per_forward <= 50
-    handle.set_option("se_fuse", 0)
-    assert handle.info().n_kernels_per_forward == 51
-    handle.set_option("se_fuse", 2)
-    assert handle.info().n_kernels_per_forward == 36
-    handle.set_option("se_fuse", 1)
+    # f16 handles drop block 1's project launch (option fold12: folded into block 2's expand weights)
+    assert i.macs_per_crop == spec.TOTAL_MACS and 35 <= i.n_kernels_per_forward <= 50
+    folded = 1 if handle.name == "f16" else 0
+    try:
+        handle.set_option("se_fuse", 0)
+        assert handle.info().n_kernels_per_forward == 51 - folded
+        handle.set_option("se_fuse", 2)
+        assert handle.info().n_kernels_per_forward == 36 - folded
+        handle.set_option("fold12", 0)
+        assert handle.info().n_kernels_per_forward == 36
+    finally:
+        handle.set_option("fold12", 1)
+        handle.set_option("se_fuse", 1)
     assert b"gfx950" in i.arch and i.compute_units >= 200
 
 
@@ -139,6 +151,36 @@ def test_mbconv_block_kernels(handle, taps, index):
         assert rel_err(r["dw"], taps[f"{p}/dw"]) < 2 * t, f"dw (front_impl={impl})"
         assert rel_err(r["gate"], taps[f"{p}/gate"].reshape(r["gate"].shape)) < 2 * t, "gate"
         assert rel_err(r["out"], taps[f"{p}/out"]) < 3 * t, "out"
+
+
+def test_block1_project_folded_into_block2_expand(handle, taps):
+    """Option fold12 (f16): block 2's front kernel reads block 1's gated depthwise output through the composed
+    project1 x expand2 weights (snapshot.cpp).  The two-step form of the same range is bitwise the per-block operators
+    chained; the folded form is the same function with other rounding points: within the kernel tolerance of the
+    two-step form and of the oracle's block-2 output.  f32 handles never fold."""
+    x = taps["stem"].astype(np.float32)
+    t = tol(handle)
+    handle.set_option("fold12", 0)
+    try:
+        two = handle.op_block_range(1, 2, x)
+    finally:
+        handle.set_option("fold12", 1)
+    chained = handle.op_block(2, handle.op_block(1, x)["out"])["out"]
+    assert np.array_equal(two, chained)
+    one = handle.op_block_range(1, 2, x)
+    if handle.name == "f32":
+        assert np.array_equal(one, two)
+    else:
+        assert not np.array_equal(one, two), "fold12 is not active on the f16 handle"
+        assert rel_err(one, two) < 2 * t
+    assert rel_err(two, taps["b2/out"]) < 4 * t and rel_err(one, taps["b2/out"]) < 4 * t
+    # a longer range across the fold, against the oracle's tap
+    assert rel_err(handle.op_block_range(1, 4, x), taps["b4/out"]) < 6 * t
+    # and ranges that do not hold both blocks are the plain blocks
+    assert np.array_equal(handle.op_block_range(2, 2, taps["b1/out"].astype(np.float32)),
+                          handle.op_block(2, taps["b1/out"].astype(np.float32))["out"])
+    with pytest.raises(ValueError):
+        handle.op_block_range(3, 2, taps["b2/out"].astype(np.float32))
 
 
 def test_head_kernels(handle, taps):
@@ -575,6 +617,15 @@ def test_front_impl_variants_end_to_end(blob, golden):
             assert np.array_equal(lm, np.concatenate([l] * 7)), impl
             outs[impl] = l
         assert np.abs(outs[2] - outs[0]).max() < 0.5 and np.abs(outs[1] - outs[0]).max() < 0.5
+        # the default schedule without the block-1 / block-2 fold: same tolerance, same invariance
+        h.set_option("front_impl", 1)
+        h.set_option("fold12", 0)
+        y, a, l = h.forward(crops)
+        assert np.abs(y - exp).max() <= F16_DEG and np.abs(l - outs[1]).max() < 0.5
+        assert not np.array_equal(l, outs[1])
+        assert np.array_equal(h.forward(crops[5:6])[2][0], l[5])
+        h.set_option("fold12", 1)
+        assert np.array_equal(h.forward(crops)[2], outs[1])
         with pytest.raises(ValueError):
             h.set_option("front_impl", 3)
 
@@ -593,7 +644,7 @@ def test_f16_accuracy_contract(blob):
     flips = np.argwhere(am != fx["argmax"])
     print(f"\n[f16, 48 crops] max {e.max():.4f} mean {e.mean():.5f} p95 {np.percentile(e, 95):.4f} deg; "
           f"{len(flips)} bin flips of {am.size}; max |logit err| {noise:.4f}")
-    assert e.max() <= 0.7 and np.percentile(e, 95) <= 0.25
+    assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.25 and e.max() <= 1.0
     assert len(flips) <= 2, flips
     lo = {0: 0, 1: 120, 2: 186}
     nb = {0: 120, 1: 66, 2: 66}
@@ -604,6 +655,70 @@ def test_f16_accuracy_contract(blob):
     with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
         y32, a32, _ = h.forward(crops)
     assert np.abs(y32 - fx["angles"]).max() <= F32_DEG
+
+
+def test_f16_error_distribution_512_crops(blob):
+    """The f16 error as a distribution: 512 seeded crops (1536 angles) against the f32 configuration of the same
+    library (itself within 1e-3 deg of the oracle), for the default schedule and without option fold12.  Measured
+    (tools/f16_error_gpu.py): default mean 0.048 / p95 0.21 / p99 0.47 / max 1.21 deg, 12 bin flips of 1536;
+    fold12=0 mean 0.055 / p95 0.24 / p99 0.52 / max 1.39, 10 flips."""
+    crops = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])
+    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h32:
+        y32, a32, l32 = h32.forward(crops)
+    for fold in (1, 0):
+        with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+            h.set_option("fold12", fold)
+            y, a, l = h.forward(crops)
+        e = np.abs(y - y32)
+        flips = int((a != a32).sum())
+        print(f"\n[f16 fold12={fold}, 512 crops vs f32] mean {e.mean():.4f} p95 {np.percentile(e, 95):.4f} "
+              f"p99 {np.percentile(e, 99):.4f} max {e.max():.4f} deg; {flips} bin flips of {a.size}")
+        assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.28 and np.percentile(e, 99) <= 0.60 and e.max() <= F16_DEG
+        assert flips <= 24                                   # 1.5 % of the bins (near ties of neighbouring bins)
+
+
+def test_no_kernel_reads_what_the_forward_did_not_write(handle):
+    """Debug option poison: every activation buffer (both block buffers, expanded / depthwise tensors, head conv output,
+    squeeze-excite partial sums and gates) is filled with NaN bit patterns before the forward starts; the results must
+    not change -- for the default schedule, one lane, and without the block-1 / block-2 fold."""
+    crops = synth.noise_crops(64, seed=9)
+    defaults = {"lanes": 3, "fold12": 1, "se_fuse": 1, "front_impl": 1}
+    try:
+        for opts in ({}, {"lanes": 1}, {"fold12": 0}, {"se_fuse": 0}, {"front_impl": 0}):
+            for k, v in opts.items():
+                handle.set_option(k, v)
+            handle.set_option("poison", 0)
+            clean = handle.forward(crops)
+            handle.set_option("poison", 1)
+            dirty = handle.forward(crops)
+            assert np.isfinite(dirty[2]).all() and all(np.array_equal(a, b) for a, b in zip(clean, dirty)), opts
+            for k in opts:
+                handle.set_option(k, defaults[k])
+    finally:
+        handle.set_option("poison", 0)
+        for k, v in defaults.items():
+            handle.set_option(k, v)
+
+
+def test_replica_engines_first_forward_under_load(blob):
+    """Regression (round 3): a replica engine's per-crop ticket counters (heads kernel) used to be zeroed by a
+    null-stream hipMemset that the engine's non-blocking stream did not wait for; with the other engines keeping the
+    GPU busy it could land in the middle of the replica's FIRST heads kernel and leave counters off by one for the
+    life of the handle -- a few of the last crops of a 512-crop batch then summed stale partial logits.  Here: fresh
+    handles, 512-crop batches submitted back to back through the ticket pipeline so that the replicas' first
+    forwards start while engine 0 is busy; every result must be the reference bits."""
+    crops = synth.noise_crops(512, seed=0)
+    with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+        ref = h.forward(crops)[2]
+    for attempt in range(3):
+        with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+            h.forward(crops[:512])                            # engine 0 sized and warm; replicas are created cold
+            h.set_option("inflight", 3)
+            for rnd in range(3):
+                tickets = [h.submit(crops) for _ in range(3)]
+                for t in tickets:
+                    y, a, l = h.collect(t, 512, want_logits=True)
+                    assert np.array_equal(l, ref), (attempt, rnd)
 
 
 def test_bench_distributed_path_one_rank():

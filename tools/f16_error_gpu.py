@@ -27,3 +27,18 @@ for name, dt, impl in (("f16 front_impl=0", _lib.F16, 0), ("f16 front_impl=1 (de
     print(f"{name:28s}: max {e.max():.4f} mean {e.mean():.5f} p95 {np.percentile(e, 95):.4f} deg; argmax flips {(a != rm).sum()} of {a.size}; "
           f"max |logit err| {np.abs(l - rl).max():.4f}")
     h.close()
+
+# Larger sample, against the f32 configuration of the same library (itself within 1e-3 deg of the oracle): the f16
+# schedule with and without option fold12 (block 1's project folded into block 2's expand weights).
+big = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])
+h32 = _lib.Handle(W.pack(w), device=0, dtype=_lib.F32)
+y32, a32, l32 = h32.forward(big)
+h32.close()
+for fold in (0, 1):
+    h = _lib.Handle(W.pack(w), device=0, dtype=_lib.F16)
+    h.set_option("fold12", fold)
+    y, a, l = h.forward(big)
+    e = np.abs(y - y32)
+    print(f"f16 fold12={fold} vs f32, 512 crops : max {e.max():.4f} mean {e.mean():.5f} p95 {np.percentile(e, 95):.4f} p99 {np.percentile(e, 99):.4f} deg; "
+          f"argmax flips {(a != a32).sum()} of {a.size}; max |logit diff| {np.abs(l - l32).max():.4f} rms {np.sqrt(((l - l32) ** 2).mean()):.5f}")
+    h.close()
