@@ -571,6 +571,8 @@ def main():
                    "world_size": world, "backend": ("nccl (RCCL)" if distributed else "none (single process)"),
                    "per_rank_crops_s": [round(x, 1) for x in per_rank],
                    "graph": not args.no_graph,
+                   "engine_options": dict(o.split("=", 1) for o in args.opt) or "defaults",
+                   "launches_per_forward": h.info().n_kernels_per_forward,
                    "forwards_in_flight": M,
                    "schedule": (f"{M} independent forwards of the batch in flight per GPU (engine option inflight={M}: "
                                 f"{M} engines round-robin, own streams/arena/graphs, one chain each); ms_per_step = "
