@@ -10,7 +10,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F16 = 0, 1
 OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EFORMAT, EHIP = 0, -2, -5, -12, -19, -22, -74, -1000
 MAX_INFLIGHT = 4

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define WHENET_ABI_VERSION 1
+/* 2 (round 3): whenet_op_trunk / whenet_op_stem_dw removed with their kernels; whenet_create_postproc and
+ * whenet_op_block_range added; options front_impl, se_fuse, fold12, poison. */
+#define WHENET_ABI_VERSION 2
 #define WHENET_API __attribute__((visibility("default")))
 
 /* return codes (negative errno-style) */
@@ -109,6 +111,8 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  output, with block 1's project conv (linear) composed into block 2's expand weights when the
  *                  snapshot is loaded -- one launch and a 112x112x16 round trip through HBM less; 0 = the two convs
  *                  as two steps.  Same function, different rounding points: results agree to f16 rounding),
+ *          "poison" (0/1, default 0, debug: the activation arena is filled with NaN bit patterns before every forward --
+ *                  a kernel that reads what the forward did not write shows up in the results),
  *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "lane_graphs" (0/1, default 0: 1 = one graph per lane launched on its own stream instead of
  *                  one forked graph; measured equal),
