@@ -358,7 +358,7 @@ def sweep_leg(blob, local_rank, dev, lanes_opt):
             els = sorted(region(nslots, steps) for _ in range(3))
             entry[key] = {"crops_s": nb * steps / els[1], "ms_per_step": els[1] / steps * 1e3, "steps": steps}
         stats = h.profile(d_crops.data_ptr(), nb, 3)
-        lanes_used = 3 if (lanes_opt <= 0 and nb >= 48) else 1
+        lanes_used = 2 if (lanes_opt <= 0 and nb >= 32) else 1
         _, _, _, _, roof, _ = summarise_profile(stats, nb / lanes_used)
         res[f"b{nb}"] = {"value": entry["inflight3"]["crops_s"], "value_serial": entry["serial"]["crops_s"],
                          "ms_per_step": entry["inflight3"]["ms_per_step"], "ms_per_step_serial": entry["serial"]["ms_per_step"],
@@ -484,7 +484,7 @@ def main():
     serial = None
     if M > 1:
         if not args.no_serial:
-            # the strictly serial schedule first (one forward at a time, 3 sub-batch lanes), for reference
+            # the strictly serial schedule first (one forward at a time, 2 sub-batch lanes), for reference
             el1, els1 = median_run(timed(1))
             serial = {"value": total_per_step * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3, "in_flight": 1,
                       "repeats": len(els1)}
@@ -512,7 +512,7 @@ def main():
     # a real kernel that IS its duration as rocprofv3's hardware timestamps report it (profiles/: the
     # kernel-trace averages agree within a few %); only for an EMPTY kernel is the ~2-9 us event/dispatch gap
     # exposed.  The chain's last entry is such an empty kernel: reported as `boundary_us`, never subtracted.
-    lanes_used = (args.lanes if args.lanes > 0 else 3)
+    lanes_used = (args.lanes if args.lanes > 0 else 2)
     while lanes_used > 1 and B // lanes_used < 16:
         lanes_used -= 1
     stats, by_kernel, dom_name, dom, roofline, boundary_us = summarise_profile(stats, B / lanes_used)
@@ -577,7 +577,7 @@ def main():
                    "schedule": (f"{M} independent forwards of the batch in flight per GPU (engine option inflight={M}: "
                                 f"{M} engines round-robin, own streams/arena/graphs, one chain each); ms_per_step = "
                                 "timed region / K, not the latency of one forward") if M > 1 else
-                               "one forward at a time, up to 3 concurrent sub-batch chains inside it"},
+                               "one forward at a time, up to 2 concurrent sub-batch chains inside it"},
         "roofline": roofline,
         "serial_schedule": serial,
         "path_fraction": {"per_gpu_crops_s": value / world,

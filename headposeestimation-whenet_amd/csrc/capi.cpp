@@ -204,7 +204,7 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
             h->inflight = int(value);
             h->next = 0;
             // several forwards in flight: each runs as ONE chain, the concurrency comes from the others
-            const long lanes = value > 1 ? 1 : 3;
+            const long lanes = value > 1 ? 1 : 2;
             e.set_option("lanes", lanes);
             for (whenet::Engine* r : h->replicas) r->set_option("lanes", lanes);
             return;

@@ -169,7 +169,9 @@ class Engine {
                                 // the faster kernel), 2 = front2.hip everywhere (f16)
     bool poison_ = false;       // debug option "poison": NaN-fill the activation arena before every forward
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
-    int lanes_ = 3;             // concurrent sub-batch chains per forward (option "lanes")
+    int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster
+                                // front kernels a third chain only adds contention: 100.1 k vs 97.2 k crops/s at batch 64,
+                                // equal from 256 crops up and for f32)
     bool lane_graphs_ = false;  // one graph per lane on its own stream instead of one forked graph (option "lane_graphs")
     int min_lane_crops_ = 16;   // do not split below this many crops per chain
     std::vector<hipStream_t> lane_streams_;

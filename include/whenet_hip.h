@@ -113,7 +113,7 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  as two steps.  Same function, different rounding points: results agree to f16 rounding),
  *          "poison" (0/1, default 0, debug: the activation arena is filled with NaN bit patterns before every forward --
  *                  a kernel that reads what the forward did not write shows up in the results),
- *          "lanes" (1..8, default 3: concurrent sub-batch chains per forward, never fewer than 16 crops each),
+ *          "lanes" (1..8, default 2: concurrent sub-batch chains per forward, never fewer than 16 crops each),
  *          "lane_graphs" (0/1, default 0: 1 = one graph per lane launched on its own stream instead of
  *                  one forked graph; measured equal),
  *          "inflight" (1..4, default 1: n > 1 gives the handle n engines -- own streams, activation
