@@ -157,3 +157,30 @@ def test_f16_set_fixture_is_the_oracle(weights):
     assert np.allclose(ref["logits"], fx["logits"][idx], rtol=1e-6, atol=1e-5)          # (stored as float32)
     assert np.array_equal(ref["argmax"], fx["argmax"][idx])
     assert fx["angles"].shape == (48, 3) and fx["logits"].shape == (48, 252)
+
+
+def test_block1_project_composed_with_block2_expand_is_the_same_function(weights, golden):
+    """The algebra behind the engine's option fold12 (csrc/snapshot.cpp, HostModel::fold12), restated in numpy float64
+    on the oracle's own tensors: block 1's project conv + BN is linear, block 2 has no skip and nothing else reads
+    block 1's output (efficientnet MBConvBlock, whenet.py:8), so
+        expand2(project1(a)) = a . (Wp1 . We2) + (bp1 . We2 + be2),       a = gate1 * depthwise1,
+    with both BatchNorms folded into their convs.  Checked against the oracle's block-2 expanded tensor."""
+    from oracle import b0_spec as G
+    w = weights
+    x = O.normalise(golden["crops"][:1]).astype(np.float64)
+    taps = {}
+    O.backbone(x, w, taps=taps)
+
+    def folded(conv, bn):
+        k = w[f"{conv}/kernel"][0, 0].astype(np.float64)                      # [K][N]
+        s = w[f"{bn}/gamma"].astype(np.float64) / np.sqrt(w[f"{bn}/var"].astype(np.float64) + G.BN_EPSILON)
+        return k * s, w[f"{bn}/beta"].astype(np.float64) - w[f"{bn}/mean"].astype(np.float64) * s
+
+    wp, bp = folded("b1/project", "b1/project_bn")                           # 32 -> 16
+    we, be = folded("b2/expand", "b2/expand_bn")                             # 16 -> 96
+    wc, bc = wp @ we, bp @ we + be
+    assert wc.shape == (32, 96)
+    a = taps["b1/dw"] * taps["b1/gate"]
+    two_step = (a @ wp + bp)
+    np.testing.assert_allclose(two_step, taps["b1/out"], rtol=0, atol=1e-10)    # block 1 has no skip
+    np.testing.assert_allclose(O.swish(a @ wc + bc), taps["b2/expand"], rtol=0, atol=1e-10)
