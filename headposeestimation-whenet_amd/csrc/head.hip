@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __rest
                                                                 float* __restrict__ logits_out, float* __restrict__ ypr,
                                                                 int32_t* __restrict__ amax, float* __restrict__ part,
                                                                 unsigned* __restrict__ count) {
-    constexpr int NTHR = 512, NW = 8, GP = 6;             // 6 position groups in the pooling
+    constexpr int NW = 8, GP = 6;                         // 6 position groups in the pooling
     __shared__ float s_gap[GP][HCH];
     __shared__ float s_feat[HCH];
     __shared__ float s_part[NW][N_LOGITS + 4];

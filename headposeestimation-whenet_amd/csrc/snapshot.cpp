@@ -244,7 +244,7 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
         const BlockSpec& b1 = m.blocks[0].spec;
         const BlockSpec& b2 = m.blocks[1].spec;
         const uint32_t K = b1.cexp(), J = b1.cout, N = b2.cexp();
-        WHENET_REQUIRE(!b1.has_expand() && !b2.has_skip() && b2.cin == J, WHENET_EFORMAT, "fold12: unexpected block layout");
+        WHENET_REQUIRE(!b1.has_expand() && !b2.has_skip() && uint32_t(b2.cin) == J, WHENET_EFORMAT, "fold12: unexpected block layout");
         const FoldedPw p1 = fold_pw(t, "b1/project", "b1/project_bn", K, J);
         const FoldedPw e2 = fold_pw(t, "b2/expand", "b2/expand_bn", J, N);
         FoldedPw c;
