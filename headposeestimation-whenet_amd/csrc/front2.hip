@@ -72,6 +72,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // quarter-rate transcendentals per value (v_exp_f32, v_rcp_f32) unpacked: 3.5 instructions per value instead of 5.5.
 // Same operations in the same order as device_math.h's swish_f<false> (x * rcp(1 + exp2(-x * log2(e)))): same bits.
 __device__ __forceinline__ float2v swish2(float2v x) {
+#ifdef WHENET_PROBE_NO_TRANSCENDENTALS          // probes only: what the kernel would take if Swish cost one multiply
+    return x * float2v{0.5f, 0.5f};
+#endif
     const float2v t = x * float2v{-1.4426950408889634f, -1.4426950408889634f};
     const float2v d = float2v{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + float2v{1.0f, 1.0f};
     return x * float2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
