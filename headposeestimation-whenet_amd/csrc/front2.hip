@@ -214,9 +214,16 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     };
     // (k beyond Cin: the packed weights are zero there, and the 16 bytes past a pixel row are the next pixel's)
     auto load_a = [&](half8 (&a)[PF], unsigned off, int ks0) {
+#ifdef WHENET_PROBE_NO_OPERANDS                  // probes only (ablation): the expand phase without its global loads
+        (void)off;
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (ks0 + u < KS) a[u] = w[0];
+#else
 #pragma unroll
         for (int u = 0; u < PF; ++u)
             if (ks0 + u < KS) a[u] = *reinterpret_cast<const half8*>(xb + off + (ks0 + u) * 32);
+#endif
     };
     STAMP(0);
     int tl = 0, rb = 0, cbk = 0;                               // the task being computed
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         float4v acc[RL];
 #pragma unroll
         for (int r = 0; r < RL; ++r) acc[r] = float4v{0.f, 0.f, 0.f, 0.f};
+#ifndef WHENET_PROBE_NO_TAPS                     // probes only (ablation): no LDS reads / MFMAs of the depthwise taps
 #pragma unroll
         for (int er = 0; er < NER; ++er) {
             half4 bv[NCH];
@@ -404,6 +412,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
                 }
             }
         }
+#endif
         const float bd_this = bdv;
         const int cb_this = cb, cq_this = cq;
         if (++cq == ncq) {                                     // the next block's taps travel during the epilogue
@@ -446,7 +455,11 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
             for (int pp = 0; pp < 2; ++pp) {
                 const int rl = 2 * pp + rP;                    // stage row of this lane's piece: 2 pp + (lane >> 5)
                 const half8 v = *reinterpret_cast<const half8*>(stg + (pp * 64 + lane) * 16);
+#ifdef WHENET_PROBE_NO_STORES                    // probes only (ablation): the output never leaves the CU
+                if (okP && rl < nr && v[0] == half_t(12345.0f)) *reinterpret_cast<half8*>(outb + obase) = v;
+#else
                 if (okP && rl < nr) *reinterpret_cast<half8*>(outb + obase + unsigned(r0 + 2 * pp) * row_bytes) = v;
+#endif
             }
             wave_lds_sync();
         }
@@ -456,6 +469,9 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         if (j == 0) s_red[cq_this * p.CC + c] = sum;
     }
     STAMP(4);
+#ifdef WHENET_PROBE_NO_SE_TAIL                   // probes only (ablation): no channel sums / reduce-conv share
+    return;
+#endif
     lds_barrier();
     STAMP(5);
 
