@@ -12,7 +12,7 @@ under torch.distributed.run (one rank per GPU, RCCL); run directly with --gpus N
 re-launches itself that way.
 
 Schedule of the timed region: K forwards of the batch, `--inflight` (default 3) of them in flight per
-GPU.  A forward is a chain of 51 dependent kernel launches (about half of a batch-64 forward is
+GPU.  A forward is a chain of 46-51 dependent kernel launches (about half of a batch-64 forward is
 launch latency), so a serving process keeps a few independent batches in flight; the library does
 that with engine option "inflight" (n engines behind one handle, round-robin, every forward in
 flight writes its own output buffers).  All K forwards complete inside the timed region (handle sync

@@ -101,7 +101,7 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
  *          "se_fuse" (0..2, default 1: second half of the squeeze-excite block inside the project conv's launch -- its
  *                  workgroups compute the gate of their own rows' crops -- 0 = never (a squeeze-excite launch per block,
- *                  51 launches per forward), 2 = on every block with a fused front kernel (36 launches), 1 = on the
+ *                  51 launches per forward, 50 with fold12), 2 = on every block with a fused front kernel (36 / 35 launches), 1 = on the
  *                  blocks where that is the faster schedule; the results are bitwise the same),
  *          "front_impl" (0..2, default 1: which fused kernel an f16 handle uses -- 0 = front.hip (depthwise taps
  *                  as f32 VALU FMAs) on every block, 2 = front2.hip (taps as Toeplitz products on the matrix
