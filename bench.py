@@ -533,8 +533,10 @@ def main():
                 traffic = v["hbm_bytes_per_launch"]
                 pmc_extra = {k2: v[k2] for k2 in ("valu_active_pct_of_wave_cycles", "valu_insts_per_wave", "mfma_busy_pct_of_cu_cycles",
                                                   "waves_per_simd", "lds_bank_conflict_pct") if k2 in v} or None
-                traffic_source = (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in separate passes "
-                                  f"(tools/pmc_round.sh), committed file -- NOT re-measured by this run")
+                traffic_source = (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_round.sh) of ONE "
+                                  f"sub-batch chain of this bench's lane geometry run alone (the counters are device-wide: "
+                                  f"with chains side by side a kernel's figures include the others' traffic); committed "
+                                  f"file -- NOT re-measured by this run")
         if traffic is not None:
             break
     roofline.update({"traffic": traffic, "traffic_source": traffic_source, "pmc": pmc_extra,

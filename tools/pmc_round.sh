@@ -4,7 +4,12 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 DT=${1:-f16}; B=${2:-64}
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --dtype $DT --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-serial --no-sweep --no-repeat --profile-iters 1 --no-graph"
+# The counters are device-wide between a kernel's start and end: with several sub-batch chains (lanes) running side
+# by side every kernel's figures would include the other chains' traffic (round 3 found the round-2 / first round-3
+# tables inflated by exactly the number of lanes).  So the passes run ONE chain of the bench's lane geometry alone:
+# batch B / 2 (the default two lanes of a B-crop forward), --lanes 1, one forward at a time.
+LB=$(( B >= 32 ? B / 2 : B ))
+CMD="python $R/bench.py --dtype $DT --batch $LB --lanes 1 --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-serial --no-sweep --no-repeat --profile-iters 1 --no-graph"
 i=0
 for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" \
