@@ -135,13 +135,92 @@ def _cpu_worker(idx, cpus, threads, secs, barrier, q):
     q.put((idx, done, el))
 
 
+def cgroup_cpu_quota():
+    """CPU quota of this process's cgroup in cores (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), walking up
+    from the process's own group; None = unlimited or unreadable."""
+    paths = []
+    try:
+        with open("/proc/self/cgroup") as f:
+            for line in f:
+                _, ctrl, rel = line.strip().split(":", 2)
+                rel = rel.lstrip("/")
+                if ctrl == "":                                      # v2 unified hierarchy
+                    d = os.path.join("/sys/fs/cgroup", rel)
+                    while True:
+                        paths.append(("v2", os.path.join(d, "cpu.max")))
+                        if os.path.normpath(d) == "/sys/fs/cgroup":
+                            break
+                        d = os.path.dirname(d)
+                elif "cpu" in ctrl.split(","):                      # v1 cpu controller
+                    d = os.path.join("/sys/fs/cgroup", ctrl, rel)
+                    paths.append(("v1", d))
+                    paths.append(("v1", os.path.join("/sys/fs/cgroup", ctrl)))
+    except (OSError, ValueError):
+        pass
+    paths += [("v2", "/sys/fs/cgroup/cpu.max"), ("v1", "/sys/fs/cgroup/cpu"), ("v1", "/sys/fs/cgroup/cpu,cpuacct")]
+    best = None
+    for kind, pth in paths:
+        try:
+            if kind == "v2":
+                with open(pth) as f:
+                    q, per = f.read().split()[:2]
+                if q == "max":
+                    continue
+                cores = float(q) / float(per)
+            else:
+                with open(os.path.join(pth, "cpu.cfs_quota_us")) as f:
+                    q = int(f.read())
+                with open(os.path.join(pth, "cpu.cfs_period_us")) as f:
+                    per = int(f.read())
+                if q <= 0:
+                    continue
+                cores = q / per
+        except (OSError, ValueError, ZeroDivisionError):
+            continue
+        best = cores if best is None else min(best, cores)
+    return best
+
+
+_SPIN = ("import sys,time\n"
+         "t0=float(sys.argv[1]); d=float(sys.argv[2])\n"
+         "while time.time()<t0: pass\n"
+         "n=0; c=time.process_time()\n"
+         "while time.time()<t0+d:\n"
+         "    for _ in range(20000): n+=1\n"
+         "print(n, time.process_time()-c)\n")
+
+
+def measured_parallelism(nproc: int, dur: float = 1.0):
+    """How many CPUs this container really gets: `nproc` interpreter processes spin over the same wall-clock window; the
+    sum of their loop counts over one process's count alone (and the sum of their CPU seconds over the window) is the
+    effective core count whatever sched_getaffinity / nproc claim (CPU quotas and steal do not show up there)."""
+    def run(k):
+        t0 = time.time() + 0.5 + 0.012 * k
+        ps = [subprocess.Popen([sys.executable, "-c", _SPIN, repr(t0), repr(dur)], stdout=subprocess.PIPE, text=True)
+              for _ in range(k)]
+        n, cpu = 0, 0.0
+        for pr in ps:
+            o = pr.communicate(timeout=120)[0].split()
+            n += int(o[0])
+            cpu += float(o[1])
+        return n, cpu
+    try:
+        n1, _ = run(1)
+        nk, cpuk = run(nproc)
+        return {"processes": nproc, "by_work": nk / max(n1, 1), "by_cpu_seconds": cpuk / dur}
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        return None
+
+
 def cpu_baseline(seconds: float):
     """Reference-faithful CPU path (oracle/whenet_torch.py: float64 normalise, batch_size=8 chunks as whenet.py:27,
     numpy decode) on the host cores of this box.  One torch process does not scale over a many-core host (batch-8
     convolutions: 8 threads are its best), so the baseline runs P processes x T = 8 threads, each pinned to its own
     CPUs (sched_setaffinity), covering HALF of the logical CPUs (the other half are mostly SMT siblings), all timed
-    over the same >= 5 s window: `value` = crops of all processes / the longest window, `cores` = P * T.
-    `single_process` is one such process alone (what round 2 reported)."""
+    over the same >= 5 s window: `value` = crops of all processes / the longest window.
+    Round 4: `cores` is what the run could actually USE -- min(threads launched, cgroup CPU quota, measured
+    parallelism of this container) -- next to `threads_launched`; round 3 printed 128 where 16 processes gave 1.15 x
+    one process (`scaling_anomaly`)."""
     import multiprocessing as mp
     try:
         avail = sorted(os.sched_getaffinity(0))
@@ -169,10 +248,27 @@ def cpu_baseline(seconds: float):
 
     d1, e1 = run(1)
     dP, eP = (d1, e1) if P == 1 else run(P)
-    return {"value": dP / eP, "unit": "crops/s", "cores": int(P * T), "kind": "port",
+    quota = cgroup_cpu_quota()
+    par = measured_parallelism(min(P * T, 128))
+    launched = int(P * T)
+    eff = float(launched)
+    if quota is not None:
+        eff = min(eff, quota)
+    if par is not None:
+        eff = min(eff, max(par["by_work"], par["by_cpu_seconds"]))
+    rate1, rateP = d1 / e1, dP / eP
+    best, best_threads = (rateP, launched) if rateP >= rate1 else (rate1, T)
+    anomaly = bool(P > 1 and rateP < 0.5 * P * rate1)
+    return {"value": best, "unit": "crops/s", "cores": int(round(min(eff, best_threads))), "kind": "port",
+            "threads_launched": launched, "effective_cores": round(eff, 1),
+            "cgroup_cpu_quota_cores": quota, "measured_parallelism": par,
+            "scaling_anomaly": anomaly,
+            "scaling_note": (f"{P} processes gave {rateP / rate1:.2f} x one process ({rateP:.1f} vs {rate1:.1f} crops/s): the host "
+                             f"does not deliver {launched} cores to this container; `cores` is the effective figure") if anomaly else None,
             "sample": f"{dP} crops as batches of 8 (whenet.py:27 batch_size=8) in {eP:.1f} s by {P} pinned processes x "
                       f"{T} threads; torch-CPU f32 restatement of whenet.py:22-34 incl. float64 normalise + numpy decode",
-            "single_process": {"value": d1 / e1, "unit": "crops/s", "cores": int(T),
+            "multi_process": {"value": rateP, "processes": P, "threads_each": T},
+            "single_process": {"value": rate1, "unit": "crops/s", "cores": int(T),
                                "sample": f"{d1} crops in {e1:.1f} s, one process, {T} threads"},
             "host_cpus": os.cpu_count() or ncpu, "usable_cpus": ncpu}
 
@@ -282,9 +378,13 @@ def swish_counts():
     return out
 
 
-def summarise_profile(stats, crops_per_launch):
+def summarise_profile(stats, crops_per_launch=None):
     """per-kernel totals of one forward's launch list + the dominant kernel's roofline object (HBM roof, and the
-    VALU roof for kernels whose floor is the Swish activations: 2 quarter-rate transcendentals per value)."""
+    VALU roof for kernels whose floor is the Swish activations: 2 quarter-rate transcendentals per value).
+    crops_per_launch: what whenet_profile() says each launch processed (ABI 3: `crops` of every entry -- with option
+    inflight > 1 a forward is ONE chain of the whole batch; round 3 assumed two lanes here and halved the VALU floor)."""
+    if crops_per_launch is None:
+        crops_per_launch = stats[0]["crops"]
     boundary_us = 0.0
     if stats and stats[-1]["kind"] == "calib":
         boundary_us = stats[-1]["avg_us"]
@@ -324,11 +424,16 @@ def summarise_profile(stats, crops_per_launch):
 
 
 def sweep_leg(blob, local_rank, dev, lanes_opt):
-    """The other north-star batch sizes (BASELINE.json: batch 1 / 8 / 64 / 512, f16): ~0.1 s timed per schedule."""
+    """The other north-star batch sizes (BASELINE.json: batch 1 / 8 / 64 / 512, f16) and the f32 parity configuration at
+    batch 64: ~0.1 s timed per schedule."""
     from whenet_hip import _lib, synth
     res = {}
-    for nb in (1, 8, 512):
-        h = _lib.Handle(blob, device=local_rank, dtype=_lib.F16)
+
+    def key_of(nb, dt):
+        return f"b{nb}" if dt == _lib.F16 else f"f32_b{nb}"
+
+    for nb, dt in ((1, _lib.F16), (8, _lib.F16), (512, _lib.F16), (64, _lib.F32)):
+        h = _lib.Handle(blob, device=local_rank, dtype=dt)
         if lanes_opt > 0:
             h.set_option("lanes", lanes_opt)
         crops = synth.noise_crops(nb, seed=100 + nb)
@@ -358,17 +463,151 @@ def sweep_leg(blob, local_rank, dev, lanes_opt):
             els = sorted(region(nslots, steps) for _ in range(3))
             entry[key] = {"crops_s": nb * steps / els[1], "ms_per_step": els[1] / steps * 1e3, "steps": steps}
         stats = h.profile(d_crops.data_ptr(), nb, 3)
-        lanes_used = 2 if (lanes_opt <= 0 and nb >= 32) else 1
-        _, _, _, _, roof, _ = summarise_profile(stats, nb / lanes_used)
-        res[f"b{nb}"] = {"value": entry["inflight3"]["crops_s"], "value_serial": entry["serial"]["crops_s"],
+        _, _, _, _, roof, _ = summarise_profile(stats)
+        res[key_of(nb, dt)] = {"value": entry["inflight3"]["crops_s"], "value_serial": entry["serial"]["crops_s"],
                          "ms_per_step": entry["inflight3"]["ms_per_step"], "ms_per_step_serial": entry["serial"]["ms_per_step"],
-                         "steps": entry["inflight3"]["steps"],
+                         "steps": entry["inflight3"]["steps"], "dtype": "f16" if dt == _lib.F16 else "f32",
                          "dominant_kernel": {"kernel": roof["kernel"], "avg_launch_us": roof["avg_launch_us"],
+                                             "crops_per_launch": stats[0]["crops"],
                                              "frac_hbm": roof["frac"], "frac_valu": roof["valu"]["frac"]}}
         h.close()
-    res["note"] = ("f16, crops resident in HBM; value = 3 forwards in flight, value_serial = one at a time; ~0.1 s timed "
-                   "per schedule (median of 3); dominant kernel from whenet_profile() at that batch")
+    res["note"] = ("crops resident in HBM; b1 / b8 / b512 = f16, f32_b64 = the parity-grade configuration (1e-3 deg, exact "
+                   "argmax) at the headline batch; value = 3 forwards in flight, value_serial = one at a time; ~0.1 s "
+                   "timed per schedule (median of 3); dominant kernel from whenet_profile() at that batch (one chain of "
+                   "`crops_per_launch` crops)")
     return res
+
+
+class Comm:
+    """What the timed region needs from the process group: a fence (barrier + device sync), the max of a host float
+    over the ranks, an all-gather of one host float per rank.  `distributed` False = one process, no group.
+    The device is whatever the group's backend moves (cuda for "nccl" = RCCL, cpu for "gloo" in tests/test_bench_dist.py,
+    which runs exactly these functions with world_size 2 and an injected forward)."""
+
+    def __init__(self, distributed: bool, device, device_sync=None):
+        self.distributed = distributed
+        self.device = device
+        self.device_sync = device_sync or (lambda: None)
+        if distributed:
+            import torch.distributed as dist
+            self.dist = dist
+            self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        else:
+            self.dist, self.world, self.rank = None, 1, 0
+
+    def fence(self):
+        if self.distributed:
+            self.dist.barrier()
+        self.device_sync()
+
+    def max_over_ranks(self, x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        if self.distributed:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, x: float):
+        if not self.distributed:
+            return [float(x)]
+        g = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(self.world)]
+        self.dist.all_gather(g, torch.tensor([x], dtype=torch.float64, device=self.device))
+        return [float(v.item()) for v in g]
+
+    def gather_ints(self, x: int):
+        return [int(round(v)) for v in self.gather(float(x))]
+
+
+def timed_steps(step, sync, comm: Comm, steps: int, warmup: int, no_repeat: bool = False):
+    """W untimed + exactly K timed steps, bracketed by comm.fence() (barrier + device synchronize) on both sides; when
+    the K steps take < 200 ms the same bracketed region is repeated (every rank the same number of times: the decision
+    is taken on the max over ranks) and every repeat is returned: [(elapsed, host_enqueue_time)] of THIS rank."""
+    def region():
+        comm.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        enq = time.perf_counter() - t0          # host time to enqueue the K steps (must stay below the elapsed time)
+        sync()
+        comm.fence()
+        return time.perf_counter() - t0, enq
+
+    for i in range(warmup):
+        step(i)
+    sync()
+    runs = [region()]
+    el0 = comm.max_over_ranks(runs[0][0])       # every rank takes the same number of repeats
+    if el0 < 0.2 and not no_repeat:
+        extra = min(40, max(2, int(0.3 / max(el0, 1e-4))))
+        extra += extra % 2                      # odd number of regions in total: the median is a measured one
+        for _ in range(extra):
+            runs.append(region())
+    return runs
+
+
+def reduce_runs(runs, comm: Comm, crops_this_rank: int, total_per_step: int, steps: int):
+    """max over ranks per repeat -> the median repeat is the job's time; per-rank figures on each rank's own clock."""
+    els = sorted(comm.max_over_ranks(r[0]) for r in runs)
+    el = els[len(els) // 2]
+    own = sorted(r[0] for r in runs)
+    el_rank = own[len(own) // 2]
+    enq = sorted(r[1] for r in runs)[len(runs) // 2]
+    return {"el": el, "els": els, "value": total_per_step * steps / el,
+            "per_rank_crops_s": comm.gather(crops_this_rank * steps / el_rank),
+            "per_rank_enqueue_ms_per_step": comm.gather(enq / steps * 1e3),
+            "per_rank_crops": comm.gather_ints(crops_this_rank),
+            "enqueue_ms_per_step": enq / steps * 1e3}
+
+
+def numa_bind(comm: Comm, local_rank: int):
+    """One rank per GPU: pin the process to the CPUs of its GPU's NUMA node (whenet_hip/shard.py), ranks that share a
+    node take disjoint slices of it.  Single-process runs are left alone (the driver's N=1 line must not depend on
+    it); WHENET_BIND_NUMA=0 / 1 forces it off / on."""
+    from whenet_hip.shard import bind_rank_to_gpu_numa, gpu_numa_cpus, gpu_pci_bus_id
+    want = os.environ.get("WHENET_BIND_NUMA")
+    if want == "0" or (want != "1" and comm.world == 1):
+        return {"bound": False, "reason": "single process" if want != "0" else "WHENET_BIND_NUMA=0"}
+    try:
+        bus = gpu_pci_bus_id(local_rank)
+    except (RuntimeError, AssertionError, AttributeError) as e:
+        return {"bound": False, "reason": f"no PCI id: {e}"[:100]}
+    node, _ = gpu_numa_cpus(bus)
+    nodes = comm.gather_ints(node)
+    same = [r for r, nd in enumerate(nodes) if nd == node]
+    return bind_rank_to_gpu_numa(bus, index_on_node=same.index(comm.rank), peers_on_node=len(same))
+
+
+def pmc_traffic(dtype: str, B: int, crops_per_launch: int, dom_name: str):
+    """HBM traffic of the dominant kernel from the committed PMC passes (tools/pmc_round.sh): only a set collected at
+    the SAME crops per launch as the profile ran is comparable with `alg_bytes_per_launch`; otherwise traffic is null
+    (round 3 printed a 32-crop figure next to 64-crop algorithmic bytes)."""
+    tried = []
+    for rnd in ("r04", "r03", "r02", "r01"):
+        rel = os.path.join("profiles", rnd, f"pmc_traffic_{dtype}_b{B}.json")
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                blob = json.load(f)
+        except (OSError, ValueError):
+            continue
+        sets = blob.get("by_crops_per_launch")
+        if sets is None:
+            tried.append(f"{rel}: no crops_per_launch recorded (pre-round-4 file) -- refused")
+            continue
+        tk = sets.get(str(crops_per_launch))
+        if tk is None:
+            tried.append(f"{rel}: holds crops_per_launch {sorted(sets)} -- not {crops_per_launch}, refused")
+            continue
+        for name, v in tk["kernels"].items():
+            if name.replace(" ", "") == dom_name.replace(" ", ""):
+                extra = {k2: v[k2] for k2 in ("valu_active_pct_of_wave_cycles", "valu_insts_per_wave", "mfma_busy_pct_of_cu_cycles",
+                                              "waves_per_simd", "lds_bank_conflict_pct", "wait_pct_of_wave_cycles",
+                                              "fetch_bytes_per_launch", "write_bytes_per_launch") if k2 in v} or None
+                src = (f"{rel} [crops_per_launch {crops_per_launch}]: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE in "
+                       f"separate passes (tools/pmc_round.sh) of ONE chain of {crops_per_launch} crops run alone (the counters "
+                       f"are device-wide: with chains side by side a kernel's figures include the others' traffic); the "
+                       f"same launch geometry whenet_profile() timed; committed file -- NOT re-measured by this run")
+                return v["hbm_bytes_per_launch"], src, extra
+        tried.append(f"{rel}: kernel {dom_name} not in the set")
+    return None, ("no PMC set matches the profiled launch (" + "; ".join(tried) + ")") if tried else None, None
 
 
 def main():
@@ -393,6 +632,8 @@ def main():
             sk.close()
             os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "1", "0"
         dist.init_process_group("nccl", device_id=dev)
+    comm = Comm(distributed, dev, torch.cuda.synchronize)
+    affinity = numa_bind(comm, local_rank)
 
     from whenet_hip import _lib, synth, weights as W
     from whenet_hip.shard import broadcast_bytes
@@ -427,57 +668,11 @@ def main():
              torch.zeros((B, 252), dtype=torch.float32, device=dev)) for _ in range(M)]
     d_ypr, d_am, d_lg = outs[0]
 
-    def fence():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def timed(nslots, hh=None, crops_ptr=None, nb=None, steps=None, warmup=None, bufs=None):
-        """W untimed + exactly K timed forwards of the same batch, `nslots` of them in flight; when the K steps
-        take < 200 ms the region is repeated (same bracket) and every repeat is returned: [(elapsed, enqueue)]."""
-        hh = hh or h
-        crops_ptr = crops_ptr or d_crops.data_ptr()
-        nb = nb or B
-        steps = steps or args.steps
-        warmup = args.warmup if warmup is None else warmup
-        bufs = bufs or outs
-
+    def timed(nslots):
         def step(i):
-            y, a, l = bufs[i % nslots]
-            hh.forward_device(crops_ptr, nb, y.data_ptr(), a.data_ptr(), l.data_ptr())
-
-        def region():
-            fence()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                step(i)
-            enq = time.perf_counter() - t0      # host time to enqueue the K steps (must stay below el)
-            hh.sync()
-            torch.cuda.synchronize()
-            fence()
-            return time.perf_counter() - t0, enq
-
-        for i in range(warmup):
-            step(i)
-        hh.sync()
-        runs = [region()]
-        el0 = max_over_ranks(runs[0][0])             # every rank takes the same number of repeats
-        if el0 < 0.2 and not args.no_repeat:
-            extra = min(40, max(2, int(0.3 / max(el0, 1e-4))))
-            extra += extra % 2                       # odd number of regions in total: the median is a measured one
-            for _ in range(extra):
-                runs.append(region())
-        return runs
-
-    def median_run(runs):
-        els = sorted(max_over_ranks(r[0]) for r in runs)
-        return els[len(els) // 2], els
+            y, a, l = outs[i % nslots]
+            h.forward_device(d_crops.data_ptr(), B, y.data_ptr(), a.data_ptr(), l.data_ptr())
+        return timed_steps(step, h.sync, comm, args.steps, args.warmup, args.no_repeat)
 
     total_per_step = args.global_batch if args.strong else world * B      # crops all ranks process per step
 
@@ -485,23 +680,14 @@ def main():
     if M > 1:
         if not args.no_serial:
             # the strictly serial schedule first (one forward at a time, 2 sub-batch lanes), for reference
-            el1, els1 = median_run(timed(1))
-            serial = {"value": total_per_step * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3, "in_flight": 1,
-                      "repeats": len(els1)}
+            r1 = reduce_runs(timed(1), comm, B, total_per_step, args.steps)
+            serial = {"value": r1["value"], "ms_per_step": r1["el"] / args.steps * 1e3, "in_flight": 1,
+                      "repeats": len(r1["els"])}
         h.set_option("inflight", M)
         if args.lanes > 0:
             h.set_option("lanes", args.lanes)
-    runs = timed(M)
-    el, els = median_run(runs)
-    own = sorted(r[0] for r in runs)
-    el_rank, enq = own[len(own) // 2], sorted(r[1] for r in runs)[len(runs) // 2]
-    value = total_per_step * args.steps / el
-    # what every rank did on its own clock (the driver computes scaling efficiency itself from `value`)
-    per_rank = [B * args.steps / el_rank]
-    if distributed:
-        g = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(g, torch.tensor([per_rank[0]], dtype=torch.float64, device=dev))
-        per_rank = [float(x.item()) for x in g]
+    res = reduce_runs(timed(M), comm, B, total_per_step, args.steps)
+    el, els, value = res["el"], res["els"], res["value"]
 
     # ---- per-kernel roofline (HIP events around every launch, same stream, eager) ----------
     stats = h.profile(d_crops.data_ptr(), B, args.profile_iters)
@@ -512,34 +698,16 @@ def main():
     # a real kernel that IS its duration as rocprofv3's hardware timestamps report it (profiles/: the
     # kernel-trace averages agree within a few %); only for an EMPTY kernel is the ~2-9 us event/dispatch gap
     # exposed.  The chain's last entry is such an empty kernel: reported as `boundary_us`, never subtracted.
-    lanes_used = (args.lanes if args.lanes > 0 else 2)
-    while lanes_used > 1 and B // lanes_used < 16:
-        lanes_used -= 1
-    stats, by_kernel, dom_name, dom, roofline, boundary_us = summarise_profile(stats, B / lanes_used)
+    crops_per_launch, chains = stats[0]["crops"], stats[0]["chains"]     # what whenet_profile() actually ran
+    stats, by_kernel, dom_name, dom, roofline, boundary_us = summarise_profile(stats)
     for st in stats:
         st["raw_us"] = st["avg_us"]
     # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in separate
     # rocprofv3 --pmc passes of this same command and committed under profiles/): per launch, bytes
-    traffic, traffic_source, pmc_extra = None, None, None
-    for rnd in ("r03", "r02", "r01"):
-        rel = os.path.join("profiles", rnd, f"pmc_traffic_{args.dtype}_b{B}.json")
-        try:
-            with open(os.path.join(ROOT, rel)) as f:
-                tk = json.load(f)["kernels"]
-        except (OSError, KeyError, ValueError):
-            continue
-        for name, v in tk.items():
-            if name.replace(" ", "") == dom_name.replace(" ", ""):
-                traffic = v["hbm_bytes_per_launch"]
-                pmc_extra = {k2: v[k2] for k2 in ("valu_active_pct_of_wave_cycles", "valu_insts_per_wave", "mfma_busy_pct_of_cu_cycles",
-                                                  "waves_per_simd", "lds_bank_conflict_pct") if k2 in v} or None
-                traffic_source = (f"{rel}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_round.sh) of ONE "
-                                  f"sub-batch chain of this bench's lane geometry run alone (the counters are device-wide: "
-                                  f"with chains side by side a kernel's figures include the others' traffic); committed "
-                                  f"file -- NOT re-measured by this run")
-        if traffic is not None:
-            break
+    traffic, traffic_source, pmc_extra = pmc_traffic(args.dtype, B, crops_per_launch, dom_name)
     roofline.update({"traffic": traffic, "traffic_source": traffic_source, "pmc": pmc_extra,
+                "traffic_over_alg_bytes": (traffic / roofline["alg_bytes_per_launch"]) if traffic else None,
+                "crops_per_launch": crops_per_launch, "chains_profiled": chains,
                 "method": "one hipEvent between consecutive launches on the chain's stream; one forward of the batch "
                           "alone on the GPU (eager pass right after the timed region), as rocprofv3's kernel trace "
                           "sees it; the timed region overlaps `forwards_in_flight` such chains",
@@ -558,7 +726,7 @@ def main():
         "repeats": len(els), "repeats_ms_per_step": [round(x / args.steps * 1e3, 4) for x in els],
         "timed_region_note": (f"{len(els)} repeats of the {args.steps}-step region (each bracketed by sync + barrier); value "
                               "and ms_per_step are the median repeat") if len(els) > 1 else "one region of K steps",
-        "host_enqueue_ms_per_step": enq / args.steps * 1e3,
+        "host_enqueue_ms_per_step": res["enqueue_ms_per_step"],
         "value_serial": serial["value"] if serial else (value if M == 1 else None),
         "ms_per_step_serial": serial["ms_per_step"] if serial else (el / args.steps * 1e3 if M == 1 else None),
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
@@ -571,7 +739,10 @@ def main():
                    "batch_per_gpu": B, "global_batch": total_per_step, "weights": "synthetic random-init seed 1234",
                    "parallelism": f"batch-shard x{world}, no data-path collective",
                    "world_size": world, "backend": ("nccl (RCCL)" if distributed else "none (single process)"),
-                   "per_rank_crops_s": [round(x, 1) for x in per_rank],
+                   "per_rank_crops_s": [round(x, 1) for x in res["per_rank_crops_s"]],
+                   "per_rank_crops": res["per_rank_crops"],
+                   "per_rank_host_enqueue_ms_per_step": [round(x, 4) for x in res["per_rank_enqueue_ms_per_step"]],
+                   "cpu_affinity": affinity,
                    "graph": not args.no_graph,
                    "engine_options": dict(o.split("=", 1) for o in args.opt) or "defaults",
                    "launches_per_forward": h.info().n_kernels_per_forward,
@@ -610,9 +781,15 @@ def main():
                     msg.append(f"slot {si}: {len(bad)} crops {bad[:12]} max |logit diff| {float((l - d_lg).abs().max()):.4g}")
             raise AssertionError("in-flight forwards differ; against a fresh forward: " + ("; ".join(msg) or "all slots equal it"))
         err = np.abs(got - ref_ang)
+        flips = int((d_am.cpu().numpy()[idx] != ref["argmax"]).sum())
         out["check"] = {"max_abs_deg_vs_f64_oracle": float(err.max()), "p95_abs_deg": float(np.percentile(err, 95)),
                         "mean_abs_deg": float(err.mean()), "crops": int(len(idx)),
-                        "argmax_flips": int((d_am.cpu().numpy()[idx] != ref["argmax"]).sum()), "bins": int(3 * len(idx))}
+                        "argmax_flips": flips, "bins": int(3 * len(idx)),
+                        # north_star: angles within 1e-3 deg of the reference AND bin argmax exactly equal
+                        "meets_north_star_parity": bool(err.max() <= 1e-3 and flips == 0),
+                        "north_star_parity_note": ("binary16 activations cannot meet 1e-3 deg / exact argmax (weight rounding alone "
+                                                   "moves angles by ~0.3 deg); the f32 configuration does -- sweep.f32_b64 carries its "
+                                                   "throughput, latency_b1 its latency") if args.dtype == "f16" else None}
     if rank == 0 and world == 1 and not args.no_latency:
         # configs[1]: batch=1 fp32 latency
         h1 = _lib.Handle(blob, device=local_rank, dtype=_lib.F32)

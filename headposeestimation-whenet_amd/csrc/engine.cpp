@@ -1,4 +1,4 @@
-#include "engine.h"
+#include "engine_internal.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -7,38 +7,7 @@
 
 namespace whenet {
 
-namespace {
-
-constexpr size_t X_ELEMS = size_t(112) * 112 * 32;    // largest block input/output per crop (stem out)
-constexpr size_t E_ELEMS = size_t(112) * 112 * 96;    // largest expanded tensor per crop (b2 expand)
-constexpr size_t D_ELEMS = size_t(56) * 56 * 144;     // largest depthwise output per crop (b3 dw)
-constexpr size_t HC_ELEMS = size_t(49) * FEAT;        // head conv output per crop
-constexpr size_t IN_BYTES = size_t(IMG) * IMG * 3;
-constexpr int MAX_GRAPHS = 16;
-
-struct DeviceGuard {
-    explicit DeviceGuard(int dev) { WHENET_HIP_CHECK(hipSetDevice(dev)); }
-};
-
-struct TempBufs {     // hipMalloc'd scratch of the single-stage entry points
-    std::vector<void*> ptrs;
-    void* get(size_t nbytes) {
-        void* p = nullptr;
-        WHENET_HIP_CHECK(hipMalloc(&p, nbytes ? nbytes : 16));
-        ptrs.push_back(p);
-        return p;
-    }
-    ~TempBufs() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
-};
-
-void copy_name(char* dst, size_t cap, const std::string& s) {
-    std::memset(dst, 0, cap);
-    std::memcpy(dst, s.data(), std::min(cap - 1, s.size()));
-}
-
-}  // namespace
+using namespace detail;
 
 // ------------------------------------------------------------------------------------------
 // construction / weights
@@ -263,20 +232,14 @@ void Engine::get_info(whenet_info_t* out) const {
     out->params_heads = params_heads_;
     out->n_tensors = n_tensors_;
     {
-        // stem + per block {expand, dw | front} {se} project + head conv + heads
+        // stem + per block {expand, dw | front} {se} project + head conv + heads: the launches enqueue_block() issues
         int k = 1 + 2;
         for (const DevBlock& b : blocks_) {
-            const bool has_expand = b.spec.expand != 1;
-            const bool front = fuse_front_ && has_expand;
-            k += front ? 1 : (has_expand ? 2 : 1);
-            {   // (project alone when it computes the gate itself: the rule of enqueue_block)
-                const bool f2 = dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
-                const int np = f2 ? b.f2plan.ntiles() * b.f2plan.chunks : b.fplan.ntiles() * b.fplan.chunks;
-                const bool pays = b.project.K < 320 && np <= 24;
-                k += (front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && pays))) ? 1 : 2;
-            }
+            const BlockSchedule bs = block_schedule(b);
+            k += bs.fused ? 1 : (b.spec.has_expand() ? 2 : 1);
+            k += bs.se_fused ? 1 : 2;                   // project alone when it computes the gate itself
         }
-        if (fold12_active()) k -= 1;              // block 1's project launch
+        if (fold12_active()) k -= 1;                    // block 1's project launch
         out->n_kernels_per_forward = k;
     }
     out->macs_per_crop = 384857312;
@@ -385,6 +348,20 @@ struct Rec {
 // front kernel reads the 112 x 112 x 32 depthwise output directly, scaling its copy of the weights by the crop's gate.
 // One launch and 77 MB of HBM traffic per 64 crops less; block 1's 16-channel output no longer exists (nothing else
 // reads it: block 2 has no skip).
+// Which kernels a block runs (options fuse_front / front_impl / se_fuse / pw_impl and the per-layer tables): ONE statement of
+// it, used by enqueue_block() and by get_info()'s launch count.
+Engine::BlockSchedule Engine::block_schedule(const DevBlock& b) const {
+    BlockSchedule r;
+    r.fused = fuse_front_ && b.spec.has_expand() && pw_impl_ == 0;
+    r.use_f2 = r.fused && dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
+    r.se_in_front = r.fused;                 // the front kernels apply the SE reduce conv to their channel sums
+    r.se_ntiles = r.use_f2 ? b.f2plan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles());
+    r.se_chunks = r.use_f2 ? b.f2plan.chunks : b.fplan.chunks;
+    const bool se_pays = b.project.K < 320 && r.se_ntiles * r.se_chunks <= 24;
+    r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && se_pays));
+    return r;
+}
+
 bool Engine::fold12_active() const {
     return fold12_ && dtype_ == WHENET_F16 && fuse_front_ && pw_impl_ == 0 && blocks_.size() >= 2 &&
            (front_impl_ == 2 || (front_impl_ == 1 && blocks_[1].f2_preferred));
@@ -409,11 +386,12 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const int hw_in = sp.h_in * sp.h_in, hw_out = sp.h_out * sp.h_out;
     const int cexp = sp.cexp();
     const void* dw_in = in;
-    int se_ntiles = b.dw.plan.ntiles();
-    const bool fused = fuse_front_ && sp.has_expand() && pw_impl_ == 0;
-    bool se_in_front = false;
-    int se_chunks = b.fplan.chunks;
-    const bool use_f2 = fused && dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
+    const BlockSchedule bs = block_schedule(b);
+    const bool fused = bs.fused, use_f2 = bs.use_f2, se_in_front = bs.se_in_front, se_fused = bs.se_fused;
+    const int se_ntiles = bs.se_ntiles, se_chunks = bs.se_chunks;
+    // (checked before anything is enqueued: a violated invariant must not leave half a block in a stream capture)
+    WHENET_REQUIRE(fold == 0 || (fold == 1 && !fused && sp.index == 1) || (fold == 2 && use_f2 && sp.index == 2), WHENET_EINVAL,
+                   "fold12: block outside the folded pair");
     if (use_f2) {
         Front2Args a{};
         a.x = in;
@@ -423,8 +401,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.bd = b.dw.bias;
         a.out = v.d;
         a.rpart = v.partial;
-        se_in_front = true;                  // the SE reduce conv is applied by the front kernel to its channel sums
-        a.w1t = b.se.w1t;
+        a.w1t = b.se.w1t;                    // the SE reduce conv is applied by the front kernel to its channel sums
         a.R = b.se.R;
         a.k = sp.k;
         a.s = sp.s;
@@ -446,9 +423,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.n = n;
         a.plan = b.f2plan;
         a.plan.threads = front2_threads(b.f2plan, n);
-        se_ntiles = b.f2plan.ntiles();
-        se_chunks = b.f2plan.chunks;
-        R(p + "/front", "front", kernel_name_front2(sp.k, sp.s, a.KSe, a.plan.threads, a.plan.xs).c_str(),
+        R(p + "/front", "front", kernel_name_front2(sp.k, sp.s, a.KSe, a.plan.threads, a.plan.xs, a.in_gate != nullptr).c_str(),
           double(n) * (hw_in * a.Cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * a.Cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front2(a, s); });
     } else if (fused) {
@@ -460,8 +435,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.bd = b.dw.bias;
         a.out = v.d;
         a.rpart = v.partial;
-        se_in_front = true;                  // the SE reduce conv is applied by the front kernel to its channel sums
-        a.w1t = b.se.w1t;
+        a.w1t = b.se.w1t;                    // the SE reduce conv is applied by the front kernel to its channel sums
         a.R = b.se.R;
         a.k = sp.k;
         a.s = sp.s;
@@ -475,7 +449,6 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.n = n;
         a.plan = b.fplan;
         a.plan.threads = front_threads(b.fplan, n);
-        se_ntiles = b.fplan.ntiles();
         R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s, a.plan.threads).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
           [&] { launch_front(a, dtype_, s); });
@@ -523,11 +496,6 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     // +12 us for blocks 3 / 2 (40 / 48 partial vectors: three dependent round trips), +4..9 us for the 14x14 blocks
     // (38-75 KB: break-even) and +24 us for the 7x7 blocks (221 KB per workgroup at ~50 GB/s per CU).  The bits are
     // the same either way.  Option se_fuse: 0 = never, 1 = where it pays (default), 2 = every fused-front block.
-    const int se_np = se_ntiles * se_chunks;
-    const bool se_pays = b.project.K < 320 && se_np <= 24;
-    WHENET_REQUIRE(fold == 0 || (fold == 1 && !fused && sp.index == 1) || (fold == 2 && use_f2 && sp.index == 2), WHENET_EINVAL,
-                   "fold12: block outside the folded pair");
-    const bool se_fused = se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && se_pays));
     SeFuse sef{};
     if (se_fused) {
         sef.rpart = v.partial;
@@ -933,236 +901,6 @@ void Engine::collect(int ticket, float* ypr, int32_t* argmax, float* logits) {
     slot->busy = false;
 }
 
-Engine::Slot* Engine::free_slot() {
-    for (Slot& s : slots_)
-        if (!s.busy) return &s;
-    throw Error(WHENET_EINVAL, "too many submissions in flight (collect one first)");
-}
-
-void Engine::ensure_slot_frame(Slot& s, size_t frame_bytes, int k) {
-    if (frame_bytes > s.frame_cap) {
-        if (s.h_frame) (void)hipHostFree(s.h_frame);
-        if (s.d_frame) (void)hipFree(s.d_frame);
-        s.h_frame = nullptr; s.d_frame = nullptr; s.frame_cap = 0;
-        WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_frame), frame_bytes, hipHostMallocDefault));
-        WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_frame), frame_bytes));
-        s.frame_cap = frame_bytes;
-    }
-    if (k > s.plan_cap) {
-        if (s.h_plan) (void)hipHostFree(s.h_plan);
-        if (s.d_plan) (void)hipFree(s.d_plan);
-        s.h_plan = nullptr; s.d_plan = nullptr; s.plan_cap = 0;
-        const size_t bytes = size_t(k) * CROP_PLAN_INTS * sizeof(int32_t);
-        WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.h_plan), bytes, hipHostMallocDefault));
-        WHENET_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s.d_plan), bytes));
-        s.plan_cap = k;
-    }
-}
-
-namespace {
-void check_rects(int fh, int fw, const int32_t* rects, int k) {
-    for (int i = 0; i < k; ++i) {
-        const int32_t* r = rects + 4 * i;
-        WHENET_REQUIRE(r[0] >= 0 && r[1] >= 0 && r[2] <= fh && r[3] <= fw && r[0] < r[2] && r[1] < r[3], WHENET_EINVAL,
-                       "crop window " + std::to_string(i) + " is empty or outside the frame");
-    }
-}
-}  // namespace
-
-// One frame of demo_video.py:49-58 as ONE submission: the frame crosses PCIe once; every head is
-// cropped / colour-swapped / resized on the device (frame.hip) straight into the forward's input.
-int Engine::submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k) {
-    DeviceGuard guard(device_);
-    require_model();
-    WHENET_REQUIRE(frame != nullptr && fh > 0 && fw > 0 && k >= 0 && (k == 0 || rects != nullptr), WHENET_EINVAL,
-                   "submit_frame: bad arguments");
-    check_rects(fh, fw, rects, k);
-    Slot* slot = free_slot();
-    if (k > 0) {
-        ensure_capacity(k);
-        ensure_slot(*slot, k);
-        const size_t fbytes = size_t(fh) * fw * 3;
-        ensure_slot_frame(*slot, fbytes, k);
-        std::memcpy(slot->h_frame, frame, fbytes);
-        for (int i = 0; i < k; ++i) build_crop_plan(rects + 4 * i, slot->h_plan + size_t(i) * CROP_PLAN_INTS);
-        const size_t N = size_t(k);
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_frame, slot->h_frame, fbytes, hipMemcpyHostToDevice, copy_stream()));
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_plan, slot->h_plan, N * CROP_PLAN_INTS * sizeof(int32_t),
-                                        hipMemcpyHostToDevice, copy_stream()));
-        WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream()));
-        WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
-        launch_crop_resize(slot->d_frame, fw, swap_rb, slot->d_plan, k, slot->d_in, stream_);
-        run_forward(slot->d_in, k, slot->d_ypr, slot->d_amax, slot->d_logits, stream_);
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_ypr, slot->d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_amax, slot->d_amax, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_logits, slot->d_logits, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    } else {
-        ensure_slot(*slot, 1);
-    }
-    WHENET_HIP_CHECK(hipEventRecord(slot->done, stream_));
-    slot->busy = true;
-    slot->n = k;
-    slot->ticket = next_ticket_++;
-    return slot->ticket;
-}
-
-void Engine::op_crop_resize(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k,
-                            uint8_t* crops_out) {
-    DeviceGuard guard(device_);
-    WHENET_REQUIRE(frame != nullptr && rects != nullptr && crops_out != nullptr && fh > 0 && fw > 0 && k > 0,
-                   WHENET_EINVAL, "op_crop_resize: bad arguments");
-    check_rects(fh, fw, rects, k);
-    std::vector<int32_t> plan(size_t(k) * CROP_PLAN_INTS);
-    for (int i = 0; i < k; ++i) build_crop_plan(rects + 4 * i, plan.data() + size_t(i) * CROP_PLAN_INTS);
-    const size_t fbytes = size_t(fh) * fw * 3, obytes = size_t(k) * IN_BYTES;
-    uint8_t* d_frame = static_cast<uint8_t*>(dev_alloc(fbytes));
-    int32_t* d_plan = static_cast<int32_t*>(dev_alloc(plan.size() * sizeof(int32_t)));
-    uint8_t* d_out = static_cast<uint8_t*>(dev_alloc(obytes));
-    try {
-        WHENET_HIP_CHECK(hipMemcpy(d_frame, frame, fbytes, hipMemcpyHostToDevice));
-        WHENET_HIP_CHECK(hipMemcpy(d_plan, plan.data(), plan.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        launch_crop_resize(d_frame, fw, swap_rb, d_plan, k, d_out, stream_);
-        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-        WHENET_HIP_CHECK(hipMemcpy(crops_out, d_out, obytes, hipMemcpyDeviceToHost));
-    } catch (...) {
-        dev_free(d_frame); dev_free(d_plan); dev_free(d_out);
-        throw;
-    }
-    dev_free(d_frame); dev_free(d_plan); dev_free(d_out);
-}
-
-// yolo_eval (yolo_v3/model.py:193-232) on host feature maps: H2D, decode + NMS on the device, the selected boxes
-// back, concatenated class by class like the reference.  Returns the number of detections.
-int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* grid_w, int num_layers,
-                      const float* anchors, int num_anchors, int num_classes, float image_h, float image_w,
-                      float score_threshold, float iou_threshold, int max_boxes, float* boxes, float* scores,
-                      int32_t* classes, int32_t* index, float* all_boxes, float* all_scores) {
-    DeviceGuard guard(device_);
-    WHENET_REQUIRE(feats && grid_h && grid_w && anchors && boxes && scores && classes, WHENET_EINVAL,
-                   "yolo_eval: NULL argument");
-    WHENET_REQUIRE((num_layers == 3 && num_anchors == 9) || (num_layers == 2 && num_anchors == 6), WHENET_EINVAL,
-                   "yolo_eval: 3 maps with 9 anchors or 2 maps with 6 (model.py:203)");
-    WHENET_REQUIRE(num_classes >= 1 && num_classes <= 1024 && image_h > 0 && image_w > 0, WHENET_EINVAL,
-                   "yolo_eval: bad num_classes / image shape");
-    WHENET_REQUIRE(max_boxes >= 1, WHENET_EINVAL, "yolo_eval: max_boxes must be >= 1");      // (any value, as model.py:193)
-    // model.py:203: anchor_mask = [[6,7,8],[3,4,5],[0,1,2]] for 3 maps, [[3,4,5],[1,2,3]] for 2
-    static const int ANCHOR_MASK3[3][3] = {{6, 7, 8}, {3, 4, 5}, {0, 1, 2}};
-    static const int ANCHOR_MASK2[2][3] = {{3, 4, 5}, {1, 2, 3}};
-    YoloArgs a{};
-    a.num_layers = num_layers;
-    a.num_classes = num_classes;
-    a.na = 3;
-    a.input_h = float(grid_h[0] * 32);                    // model.py:204
-    a.input_w = float(grid_w[0] * 32);
-    a.image_h = image_h;
-    a.image_w = image_w;
-    {   // model.py:158-162, float32 like the graph: new_shape = round(image_shape * min(input_shape / image_shape))
-        const float ry = a.input_h / image_h, rx = a.input_w / image_w;
-        const float r = ry < rx ? ry : rx;
-        const float new_h = std::nearbyintf(image_h * r), new_w = std::nearbyintf(image_w * r);      // half to even
-        a.off_y = (a.input_h - new_h) / 2.0f / a.input_h;
-        a.off_x = (a.input_w - new_w) / 2.0f / a.input_w;
-        a.scale_y = a.input_h / new_h;
-        a.scale_x = a.input_w / new_w;
-    }
-    a.score_thr = score_threshold;
-    a.iou_thr = iou_threshold;
-    // one engine-owned scratch block, grown on demand (round 2 paid ~10 hipMalloc/hipFree per frame here)
-    struct Carver {
-        Engine* e;
-        size_t used = 0;
-        std::vector<std::pair<size_t, size_t>> pieces;           // (offset, bytes)
-        size_t add(size_t nbytes) {
-            const size_t off = (used + 255) & ~size_t(255);
-            used = off + (nbytes ? nbytes : 16);
-            return off;
-        }
-    };
-    int N = 0;
-    const size_t per = size_t(5 + num_classes) * 3;
-    size_t feat_off[3] = {0, 0, 0}, feat_bytes[3] = {0, 0, 0};
-    Carver cv{this};
-    for (int l = 0; l < num_layers; ++l) {
-        WHENET_REQUIRE(feats[l] && grid_h[l] > 0 && grid_w[l] > 0 && grid_h[l] <= 4096 && grid_w[l] <= 4096, WHENET_EINVAL,
-                       "yolo_eval: bad feature map");
-        YoloLayer& L = a.layer[l];
-        L.gh = grid_h[l];
-        L.gw = grid_w[l];
-        L.first = N;
-        for (int k = 0; k < 3; ++k) {
-            const int m = (num_layers == 3) ? ANCHOR_MASK3[l][k] : ANCHOR_MASK2[l][k];
-            L.anchor[k][0] = anchors[2 * m];
-            L.anchor[k][1] = anchors[2 * m + 1];
-        }
-        feat_bytes[l] = size_t(L.gh) * L.gw * per * sizeof(float);
-        feat_off[l] = cv.add(feat_bytes[l]);
-        N += L.gh * L.gw * 3;
-    }
-    a.N = N;
-    a.NP = 1;
-    while (a.NP < N) a.NP <<= 1;
-    if (max_boxes > N) max_boxes = N;                       // (no more selections than boxes)
-    a.max_boxes = max_boxes;
-    const size_t C = size_t(num_classes), MB = size_t(max_boxes);
-    const size_t o_boxes = cv.add(size_t(N) * 4 * sizeof(float));
-    const size_t o_all = all_scores ? cv.add(size_t(N) * C * sizeof(float)) : 0;
-    const size_t o_counts = cv.add(C * sizeof(int));
-    const size_t o_keys = cv.add(C * size_t(a.NP) * sizeof(unsigned long long));
-    const size_t o_ob = cv.add(C * MB * 4 * sizeof(float));
-    const size_t o_os = cv.add(C * MB * sizeof(float));
-    const size_t o_oi = cv.add(C * MB * sizeof(int));
-    const size_t o_oc = cv.add(C * sizeof(int));
-    if (cv.used > yolo_scratch_bytes_) {
-        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-        if (yolo_scratch_) (void)hipFree(yolo_scratch_);
-        yolo_scratch_ = nullptr;
-        yolo_scratch_bytes_ = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&yolo_scratch_), cv.used);
-        if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("yolo_eval scratch: ") + hipGetErrorString(e));
-        yolo_scratch_bytes_ = cv.used;
-    }
-    unsigned char* base = yolo_scratch_;
-    for (int l = 0; l < num_layers; ++l) {
-        float* d = reinterpret_cast<float*>(base + feat_off[l]);
-        WHENET_HIP_CHECK(hipMemcpyAsync(d, feats[l], feat_bytes[l], hipMemcpyHostToDevice, stream_));
-        a.layer[l].feats = d;
-    }
-    a.boxes = reinterpret_cast<float*>(base + o_boxes);
-    a.all_scores = all_scores ? reinterpret_cast<float*>(base + o_all) : nullptr;
-    a.counts = reinterpret_cast<int*>(base + o_counts);
-    a.keys = reinterpret_cast<unsigned long long*>(base + o_keys);
-    a.out_boxes = reinterpret_cast<float*>(base + o_ob);
-    a.out_scores = reinterpret_cast<float*>(base + o_os);
-    a.out_index = reinterpret_cast<int*>(base + o_oi);
-    a.out_count = reinterpret_cast<int*>(base + o_oc);
-    launch_yolo_eval(a, stream_);
-    std::vector<float> hb(C * MB * 4), hs(C * MB);
-    std::vector<int> hi(C * MB), hc(C);
-    WHENET_HIP_CHECK(hipMemcpyAsync(hb.data(), a.out_boxes, hb.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipMemcpyAsync(hs.data(), a.out_scores, hs.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipMemcpyAsync(hi.data(), a.out_index, hi.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipMemcpyAsync(hc.data(), a.out_count, hc.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    if (all_boxes)
-        WHENET_HIP_CHECK(hipMemcpyAsync(all_boxes, a.boxes, size_t(N) * 4 * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (all_scores)
-        WHENET_HIP_CHECK(hipMemcpyAsync(all_scores, a.all_scores, size_t(N) * C * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    int out = 0;                                          // model.py:227-229: concatenated class by class
-    for (size_t c = 0; c < C; ++c)
-        for (int k = 0; k < hc[c]; ++k, ++out) {
-            std::memcpy(boxes + size_t(out) * 4, hb.data() + (c * MB + size_t(k)) * 4, 4 * sizeof(float));
-            scores[out] = hs[c * MB + size_t(k)];
-            classes[out] = int32_t(c);
-            if (index) index[out] = hi[c * MB + size_t(k)];
-        }
-    return out;
-}
-
-// Per-launch timing of the forward AS THE TIMED PATH RUNS IT: the same sub-batch chains on the
-// same streams, concurrently, launched eagerly with one HIP event recorded on the chain's stream
-// between consecutive kernels (a launch's time = previous event -> its own event, i.e. kernel plus
-// the boundary in front of it).  Entries: one per launch of a chain; durations averaged over the
-// chains and the iterations; bytes / flops are those of ONE chain's launch (its sub-batch).
 int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat_t* stats, int cap) {
     DeviceGuard guard(device_);
     require_model();
@@ -1232,170 +970,10 @@ int Engine::profile(const uint8_t* d_crops, int n, int iters, whenet_launch_stat
         o.avg_us = tot * 1000.0 / (double(iters) * lanes);
         o.alg_bytes = e.bytes;
         o.alg_flops = e.flops;
+        o.crops = n / lanes + (0 < n % lanes ? 1 : 0);       // (chain 0's sub-batch: what bytes / flops are counted for)
+        o.chains = lanes;
     }
     return count;
-}
-
-// ------------------------------------------------------------------------------------------
-// single-stage entry points (tests)
-// ------------------------------------------------------------------------------------------
-void Engine::op_stem(const uint8_t* crops, int n, float* out) {
-    DeviceGuard guard(device_);
-    require_model();
-    WHENET_REQUIRE(crops && out, WHENET_EINVAL, "op_stem: NULL argument");
-    ensure_capacity(n);
-    TempBufs tmp;
-    const size_t N = size_t(n);
-    float* d_out = static_cast<float*>(tmp.get(N * X_ELEMS * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
-    StemArgs a{in_u8_, x0_, d_stem_w_, d_stem_b_, d_lut_, n};
-    launch_stem(a, dtype_, stream_);
-    launch_act_to_f32(x0_, d_out, N * X_ELEMS, dtype_, stream_);
-    WHENET_HIP_CHECK(hipMemcpyAsync(out, d_out, N * X_ELEMS * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_block(int index, const float* in, int n, float* expand_out, float* dw_out, float* gate, float* out) {
-    DeviceGuard guard(device_);
-    require_model();
-    WHENET_REQUIRE(index >= 1 && index <= int(blocks_.size()), WHENET_EINVAL, "op_block: index must be 1..16");
-    WHENET_REQUIRE(in != nullptr, WHENET_EINVAL, "op_block: NULL input");
-    ensure_capacity(n);
-    const DevBlock& b = blocks_[size_t(index - 1)];
-    const BlockSpec& sp = b.spec;
-    const size_t N = size_t(n);
-    const size_t in_elems = N * sp.h_in * sp.h_in * sp.cin;
-    const size_t exp_elems = N * sp.h_in * sp.h_in * sp.cexp();
-    const size_t dw_elems = N * sp.h_out * sp.h_out * sp.cexp();
-    const size_t out_elems = N * sp.h_out * sp.h_out * sp.cout;
-    TempBufs tmp;
-    float* d_f32 = static_cast<float*>(tmp.get(std::max({in_elems, exp_elems, dw_elems, out_elems}) * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
-    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
-    WHENET_HIP_CHECK(hipMemsetAsync(gate_, 0xff, N * 1152 * sizeof(float), stream_));     // (NaN unless a launch writes it)
-    enqueue_block(b, view(0), x0_, x1_, n, stream_, nullptr);
-    auto fetch = [&](const void* src, size_t elems, float* dst) {
-        if (!dst) return;
-        launch_act_to_f32(src, d_f32, elems, dtype_, stream_);
-        WHENET_HIP_CHECK(hipMemcpyAsync(dst, d_f32, elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    };
-    if (sp.has_expand()) fetch(e_, exp_elems, expand_out);
-    fetch(d_, dw_elems, dw_out);
-    if (gate) {
-        fetch(gate_, N * sp.cexp(), gate);         // (stored in the activation type: see se.hip)
-    }
-    fetch(x1_, out_elems, out);
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_block_range(int first, int last, const float* in, int n, float* out) {
-    DeviceGuard guard(device_);
-    require_model();
-    WHENET_REQUIRE(first >= 1 && first <= last && last <= int(blocks_.size()), WHENET_EINVAL,
-                   "op_block_range: need 1 <= first <= last <= 16");
-    WHENET_REQUIRE(in != nullptr && out != nullptr, WHENET_EINVAL, "op_block_range: NULL buffer");
-    ensure_capacity(n);
-    const BlockSpec& si = blocks_[size_t(first - 1)].spec;
-    const BlockSpec& so = blocks_[size_t(last - 1)].spec;
-    const size_t in_elems = size_t(n) * si.h_in * si.h_in * si.cin;
-    const size_t out_elems = size_t(n) * so.h_out * so.h_out * so.cout;
-    TempBufs tmp;
-    float* d_f32 = static_cast<float*>(tmp.get(std::max(in_elems, out_elems) * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
-    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
-    const View v = view(0);
-    const void* res = enqueue_blocks(first, last, v, v.x0, n, stream_, nullptr);
-    launch_act_to_f32(res, d_f32, out_elems, dtype_, stream_);
-    WHENET_HIP_CHECK(hipMemcpyAsync(out, d_f32, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_head(const float* in, int n, float* feat, float* logits, float* ypr, int32_t* argmax) {
-    DeviceGuard guard(device_);
-    require_model();
-    WHENET_REQUIRE(in != nullptr, WHENET_EINVAL, "op_head: NULL input");
-    ensure_capacity(n);
-    const size_t N = size_t(n);
-    const size_t in_elems = N * 49 * 320;
-    TempBufs tmp;
-    float* d_f32 = static_cast<float*>(tmp.get(in_elems * sizeof(float)));
-    float* d_feat = static_cast<float*>(tmp.get(N * FEAT * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
-    launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
-    PwArgs a{};
-    a.a = x0_;
-    a.wp = head_.wp;
-    a.wdense = head_.wdense;
-    a.bias = head_.bias;
-    a.out = hc_;
-    a.M = n * 49;
-    a.K = head_.K;
-    a.N = head_.N;
-    a.KS = head_.KS;
-    a.NTILES = head_.NTILES;
-    a.HW = 49;
-    a.act = ACT_SWISH;
-    launch_pw(a, dtype_, pw_impl_, num_cus_, stream_);
-    HeadsArgs h{};
-    h.x = hc_;
-    h.w = d_dense_w_;
-    h.b = d_dense_b_;
-    h.feat = d_feat;
-    h.logits = o_logits_;
-    h.ypr = o_ypr_;
-    h.argmax = o_amax_;
-    h.n = n;
-    launch_heads(h, dtype_, stream_);
-    if (feat) WHENET_HIP_CHECK(hipMemcpyAsync(feat, d_feat, N * FEAT * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (logits) WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (ypr) WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_decode(const float* logits, int n, float* ypr, int32_t* argmax) {
-    DeviceGuard guard(device_);
-    require_model();
-    WHENET_REQUIRE(logits && ypr, WHENET_EINVAL, "op_decode: NULL argument");
-    ensure_capacity(n);
-    const size_t N = size_t(n);
-    TempBufs tmp;
-    float* d_lg = static_cast<float*>(tmp.get(N * N_LOGITS * sizeof(float)));
-    WHENET_HIP_CHECK(hipMemcpyAsync(d_lg, logits, N * N_LOGITS * sizeof(float), hipMemcpyHostToDevice, stream_));
-    HeadsArgs h{};
-    h.logits_in = d_lg;
-    h.w = d_dense_w_;
-    h.b = d_dense_b_;
-    h.ypr = o_ypr_;
-    h.argmax = o_amax_;
-    h.n = n;
-    launch_heads(h, WHENET_F32, stream_);
-    WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-// ------------------------------------------------------------------------------------------
-void* Engine::dev_alloc(size_t nbytes) {
-    DeviceGuard guard(device_);
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, nbytes ? nbytes : 16);
-    if (e != hipSuccess) throw Error(WHENET_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
-    return p;
-}
-void Engine::dev_free(void* p) {
-    DeviceGuard guard(device_);
-    if (p) WHENET_HIP_CHECK(hipFree(p));
-}
-void Engine::h2d(void* d, const void* s, size_t nbytes) {
-    DeviceGuard guard(device_);
-    WHENET_HIP_CHECK(hipMemcpy(d, s, nbytes, hipMemcpyHostToDevice));
-}
-void Engine::d2h(void* d, const void* s, size_t nbytes) {
-    DeviceGuard guard(device_);
-    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
-    WHENET_HIP_CHECK(hipMemcpy(d, s, nbytes, hipMemcpyDeviceToHost));
 }
 
 }  // namespace whenet

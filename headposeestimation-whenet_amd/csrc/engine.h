@@ -142,6 +142,11 @@ class Engine {
     // blocks first..last (1-based) as the forward pass runs them; returns the buffer (x0 / x1 of `v`) holding the result
     void* enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec);
     bool fold12_active() const;
+    struct BlockSchedule {     // which kernels a block runs under the current options
+        bool fused = false, use_f2 = false, se_in_front = false, se_fused = false;
+        int se_ntiles = 1, se_chunks = 1;
+    };
+    BlockSchedule block_schedule(const DevBlock& b) const;
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
     void ensure_slot(Slot& s, int n);
@@ -206,6 +211,7 @@ class Engine {
     size_t partial_per_crop_ = 0;
     unsigned char* yolo_scratch_ = nullptr;      // device scratch of yolo_eval, grown on demand
     size_t yolo_scratch_bytes_ = 0;
+    std::vector<int> yolo_counts_;               // host staging of the per-class detection counts
 
     std::map<GraphKey, hipGraphExec_t> graphs_;
 

@@ -26,6 +26,7 @@
 #include "kernels.h"
 #include "stamps.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -324,13 +325,14 @@ template <typename T, int K, int S, int NTHR>
 void launch_t(const FrontArgs& a, hipStream_t stream) {
     const FrontPlan& p = a.plan;
     dim3 grid(p.tiles_x * p.tiles_y, p.chunks, a.n);
-    static bool attr[64] = {};
+    WHENET_REQUIRE(p.lds_bytes <= 160 * 1024, WHENET_EINVAL, "front: the tile plan needs more than 160 KB of LDS");
+    static std::atomic<bool> attr[64];           // (zero-initialised; handles are one per host thread)
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
-    if (p.lds_bytes > 64 * 1024 && dev >= 0 && dev < 64 && !attr[dev]) {
+    if (p.lds_bytes > 64 * 1024 && dev >= 0 && dev < 64 && !attr[dev].load(std::memory_order_acquire)) {
         WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S, NTHR>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr[dev] = true;
+        attr[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
@@ -504,7 +506,8 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
     std::vector<double> scores;
     const std::vector<FrontPlan> cand = plan_front_candidates(dtype, k, s, H, Ho, Cexp, &scores);
     WHENET_REQUIRE(!cand.empty(), WHENET_EINVAL, "front: no tile plan fits");
-    if (dtype == WHENET_F16 && !getenv("WHENET_FRONT_NO_TUNED")) {
+    static const bool no_tuned = getenv("WHENET_FRONT_NO_TUNED") != nullptr;       // (probes only; read once)
+    if (dtype == WHENET_F16 && !no_tuned) {
         for (const TunedPlan& t : TUNED_F16)
             if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp)
                 for (const FrontPlan& p : cand)
@@ -521,7 +524,8 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
 // (<= 2 workgroups per CU) the kernel is one workgroup's critical path, so 8 waves shorten it;
 // beyond that 4-wave workgroups pack the CUs better.
 int front_threads(const FrontPlan& p, int n) {
-    if (const char* e = getenv("WHENET_FRONT_THREADS")) return atoi(e);       // probes only
+    static const int forced = [] { const char* e = getenv("WHENET_FRONT_THREADS"); return e ? atoi(e) : 0; }();   // probes only
+    if (forced) return forced;
     return (long(n) * p.ntiles() * p.chunks <= 512) ? 512 : 256;
 }
 

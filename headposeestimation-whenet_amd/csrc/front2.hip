@@ -34,6 +34,7 @@
 #include "kernels.h"
 #include "stamps.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -72,9 +73,6 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // quarter-rate transcendentals per value (v_exp_f32, v_rcp_f32) unpacked: 3.5 instructions per value instead of 5.5.
 // Same operations in the same order as device_math.h's swish_f<false> (x * rcp(1 + exp2(-x * log2(e)))): same bits.
 __device__ __forceinline__ float2v swish2(float2v x) {
-#ifdef WHENET_PROBE_NO_TRANSCENDENTALS          // probes only: what the kernel would take if Swish cost one multiply
-    return x * float2v{0.5f, 0.5f};
-#endif
     const float2v t = x * float2v{-1.4426950408889634f, -1.4426950408889634f};
     const float2v d = float2v{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + float2v{1.0f, 1.0f};
     return x * float2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
@@ -110,7 +108,8 @@ __device__ __forceinline__ float quad_xor2(float v) {      // DPP quad_perm [2,3
 
 // XS: the tile's x origin is moved XS pixels to the left (7-wide 5x5 layers: XS = 2 puts image column 0 on a group
 // boundary -- 8 instead of 12 pixel slots per row in the expand -- at the price of one more Toeplitz chunk).
-template <int K, int S, int KS, int NTHR, int XS>
+// GATED: the expand contracts (in_gate[crop] * x) -- block 2 fed by block 1's depthwise output (option fold12).
+template <int K, int S, int KS, int NTHR, int XS, bool GATED>
 __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     constexpr int NCH = (3 * S + K + XS + 3) / 4;     // 4-pixel input chunks a 4-pixel output group reads
     constexpr int NER = (RL - 1) * S + K;             // input rows of a column
@@ -181,8 +180,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     // depthwise output; the gate scales the contraction index, so it is applied to this crop's copy of the weights
     // instead of to every pixel row -- in f32 (f32 composed weights x f32 gate, ONE rounding to f16 per weight; the
     // two-step form rounds the gate, the gated activation, both weight matrices and block 1's output).
-    // (compile-time: the shape 3x3 / stride 2 / Cin 32 exists only as that folded block 2 -- no registers elsewhere)
-    constexpr bool GATED = (K == 3 && S == 2 && KS == 2);
+    // (a template parameter: the gate rows cost KS x 8 registers, only the folded block 2 pays them)
     float4v gq[GATED ? KS : 1][2];
     if constexpr (GATED) {
         const float* gp = reinterpret_cast<const float*>(p.in_gate) + size_t(b) * Cin + g * 8;
@@ -212,18 +210,18 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         const int ch = tl * 32 + lm;
         bias_cur = (ch < ccur) ? p.be[c0 + ch] : 0.f;
     };
-    // (k beyond Cin: the packed weights are zero there, and the 16 bytes past a pixel row are the next pixel's)
+    // k beyond Cin (Cin = 24 / 40: the upper half of the last k-step): the packed weights are zero there, but the 16
+    // bytes past a pixel row are the next pixel's channels -- or, for the last pixel of the last crop, whatever follows
+    // the tensor: 0 x NaN would poison the accumulators, so those lanes' operand is zeroed (one v_cndmask per dword on
+    // the last k-step of the two layers concerned; same bits wherever the bytes were finite)
+    const bool ktail = (Cin & 15) != 0 && g == 1;
     auto load_a = [&](half8 (&a)[PF], unsigned off, int ks0) {
-#ifdef WHENET_PROBE_NO_OPERANDS                  // probes only (ablation): the expand phase without its global loads
-        (void)off;
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            if (ks0 + u < KS) a[u] = w[0];
-#else
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (ks0 + u < KS) a[u] = *reinterpret_cast<const half8*>(xb + off + (ks0 + u) * 32);
-#endif
+            if (ks0 + u < KS) {
+                a[u] = *reinterpret_cast<const half8*>(xb + off + (ks0 + u) * 32);
+                if (ks0 + u == KS - 1 && ktail) a[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
     };
     STAMP(0);
     int tl = 0, rb = 0, cbk = 0;                               // the task being computed
@@ -396,7 +394,6 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         float4v acc[RL];
 #pragma unroll
         for (int r = 0; r < RL; ++r) acc[r] = float4v{0.f, 0.f, 0.f, 0.f};
-#ifndef WHENET_PROBE_NO_TAPS                     // probes only (ablation): no LDS reads / MFMAs of the depthwise taps
 #pragma unroll
         for (int er = 0; er < NER; ++er) {
             half4 bv[NCH];
@@ -412,7 +409,6 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
                 }
             }
         }
-#endif
         const float bd_this = bdv;
         const int cb_this = cb, cq_this = cq;
         if (++cq == ncq) {                                     // the next block's taps travel during the epilogue
@@ -455,11 +451,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
             for (int pp = 0; pp < 2; ++pp) {
                 const int rl = 2 * pp + rP;                    // stage row of this lane's piece: 2 pp + (lane >> 5)
                 const half8 v = *reinterpret_cast<const half8*>(stg + (pp * 64 + lane) * 16);
-#ifdef WHENET_PROBE_NO_STORES                    // probes only (ablation): the output never leaves the CU
-                if (okP && rl < nr && v[0] == half_t(12345.0f)) *reinterpret_cast<half8*>(outb + obase) = v;
-#else
                 if (okP && rl < nr) *reinterpret_cast<half8*>(outb + obase + unsigned(r0 + 2 * pp) * row_bytes) = v;
-#endif
             }
             wave_lds_sync();
         }
@@ -469,9 +461,6 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         if (j == 0) s_red[cq_this * p.CC + c] = sum;
     }
     STAMP(4);
-#ifdef WHENET_PROBE_NO_SE_TAIL                   // probes only (ablation): no channel sums / reduce-conv share
-    return;
-#endif
     lds_barrier();
     STAMP(5);
 
@@ -515,7 +504,13 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
 
 namespace {
 
-template <int K, int S, int KS, int NTHR, int XS = 0>
+// hipFuncSetAttribute once per (instantiation, device); handles are one per host thread, so the flag is atomic
+struct OncePerDevice {
+    std::atomic<bool> done[64];
+    OncePerDevice() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
+};
+
+template <int K, int S, int KS, int NTHR, int XS = 0, bool GATED = false>
 void launch_f2(const Front2Args& a, hipStream_t stream) {
     const Front2Plan& pl = a.plan;
     F2Params p{};
@@ -533,15 +528,17 @@ void launch_f2(const Front2Args& a, hipStream_t stream) {
     p.EH = pl.EH;  p.EWp = pl.EWp;  p.RP = pl.RP;  p.CP = pl.CP;
     p.off_stage = pl.off_stage;  p.off_red = pl.off_red;  p.off_sum = pl.off_sum;
     p.R = a.R;  p.RPse = (a.R + 3) & ~3;
-    static bool attr[64] = {};
+    WHENET_REQUIRE(pl.lds_bytes <= 160 * 1024, WHENET_EINVAL, "front2: the tile plan needs more than 160 KB of LDS");
+    static OncePerDevice attr;
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr[dev]) {
-        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front2_kernel<K, S, KS, NTHR, XS>),
+    if (dev >= 0 && dev < 64 && !attr.done[dev].load(std::memory_order_acquire)) {
+        // (two threads may both get here: the call is idempotent, the flag only saves repeating it)
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front2_kernel<K, S, KS, NTHR, XS, GATED>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr[dev] = true;
+        attr.done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((whenet_front2_kernel<K, S, KS, NTHR, XS>), dim3(pl.tiles_x * pl.tiles_y, pl.chunks, a.n), dim3(NTHR),
+    hipLaunchKernelGGL((whenet_front2_kernel<K, S, KS, NTHR, XS, GATED>), dim3(pl.tiles_x * pl.tiles_y, pl.chunks, a.n), dim3(NTHR),
                        pl.lds_bytes, stream, p);
     WHENET_HIP_CHECK(hipGetLastError());
 }
@@ -551,7 +548,10 @@ void launch_f2_shape(const Front2Args& a, hipStream_t stream) {
     const int key = a.k * 1000 + a.s * 100 + a.KSe + a.plan.xs * 10000;
     switch (key) {                                   // EfficientNet-B0's eleven (kernel, stride, Cin / 16) shapes
         case 3201: launch_f2<3, 2, 1, NTHR>(a, stream); break;       // b2
-        case 3202: launch_f2<3, 2, 2, NTHR>(a, stream); break;       // b2 fed by block 1's depthwise output (fold12)
+        case 3202:                                                   // Cin 17..32: b2 fed by block 1's depthwise output (fold12)
+            if (a.in_gate != nullptr) launch_f2<3, 2, 2, NTHR, 0, true>(a, stream);
+            else launch_f2<3, 2, 2, NTHR>(a, stream);
+            break;
         case 3102: launch_f2<3, 1, 2, NTHR>(a, stream); break;       // b3
         case 5202: launch_f2<5, 2, 2, NTHR>(a, stream); break;       // b4
         case 5103: launch_f2<5, 1, 3, NTHR>(a, stream); break;       // b5
@@ -626,7 +626,8 @@ const Tuned2 TUNED2[] = {
 }  // namespace
 
 Front2Plan plan_front2(int k, int s, int H, int Ho, int Cexp) {
-    if (!getenv("WHENET_FRONT_NO_TUNED"))
+    static const bool no_tuned = getenv("WHENET_FRONT_NO_TUNED") != nullptr;       // (probes only; read once)
+    if (!no_tuned)
         for (const Tuned2& t : TUNED2)
             if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp) return make_front2_plan(k, s, Ho, Cexp, t.CC, t.TH, t.TXG, t.threads, t.xs);
     // shapes outside the table: 32 channels, 7 rows, the widest tile that leaves two workgroups per CU
@@ -669,15 +670,15 @@ std::vector<Front2Plan> plan_front2_candidates(int k, int s, int Ho, int Cexp) {
 // 228 us at 256 crops, 57.5 vs 59.2 at 64); everywhere else they are equal or slower (b4: 178 vs 118 us at 256 crops).
 // Same bits either way: a wave's share of tasks / items changes, not what a task or an item computes.
 int front2_threads(const Front2Plan& p, int n) {
-    if (const char* e = getenv("WHENET_FRONT_THREADS")) return atoi(e);       // probes only
+    static const int forced = [] { const char* e = getenv("WHENET_FRONT_THREADS"); return e ? atoi(e) : 0; }();   // probes only
     (void)n;
-    return p.threads;
+    return forced ? forced : p.threads;
 }
 
 void launch_front2(const Front2Args& a, hipStream_t stream) {
     WHENET_REQUIRE(a.KSe == ceil_div(a.Cin, 16), WHENET_EINVAL, "front2: k-steps do not match Cin");
-    WHENET_REQUIRE((a.in_gate != nullptr) == (a.k == 3 && a.s == 2 && a.KSe == 2) && (a.in_gate == nullptr || a.Cin == 32),
-                   WHENET_EINVAL, "front2: the gated-input form is the 3x3 / stride-2 / Cin = 32 shape, and only that");
+    WHENET_REQUIRE(a.in_gate == nullptr || (a.k == 3 && a.s == 2 && a.KSe == 2 && a.Cin == 32), WHENET_EINVAL,
+                   "front2: the gated-input form exists for the 3x3 / stride-2 / Cin = 32 shape only");
     Front2Args b = a;
     if (b.plan.threads != 256) {              // the stage / sums offsets depend on the wave count
         b.plan = make_front2_plan(a.k, a.s, a.Ho, a.Cexp, a.plan.CC, a.plan.TH, a.plan.TXG, a.plan.threads, a.plan.xs);
@@ -686,9 +687,9 @@ void launch_front2(const Front2Args& a, hipStream_t stream) {
     else launch_f2_shape<256>(b, stream);
 }
 
-std::string kernel_name_front2(int k, int s, int kse, int threads, int xs) {
+std::string kernel_name_front2(int k, int s, int kse, int threads, int xs, bool gated) {
     return "whenet_front2_kernel<" + std::to_string(k) + ", " + std::to_string(s) + ", " + std::to_string(kse) + ", " +
-           std::to_string(threads) + ", " + std::to_string(xs) + ">";
+           std::to_string(threads) + ", " + std::to_string(xs) + ", " + (gated ? "true" : "false") + ">";
 }
 
 }  // namespace whenet

@@ -200,7 +200,7 @@ struct Front2Args {
     Front2Plan plan;
 };
 void launch_front2(const Front2Args& a, hipStream_t stream);
-std::string kernel_name_front2(int k, int s, int kse, int threads, int xs);
+std::string kernel_name_front2(int k, int s, int kse, int threads, int xs, bool gated);
 
 // ---- yolo.hip ---------------------------------------------------------------------------
 // YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.

@@ -10,7 +10,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, F16 = 0, 1
 OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EFORMAT, EHIP = 0, -2, -5, -12, -19, -22, -74, -1000
 MAX_INFLIGHT = 4
@@ -30,7 +30,8 @@ class Info(C.Structure):
 
 class LaunchStat(C.Structure):
     _fields_ = [("layer", C.c_char * 32), ("kind", C.c_char * 16), ("kernel", C.c_char * 64),
-                ("avg_us", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double)]
+                ("avg_us", C.c_double), ("alg_bytes", C.c_double), ("alg_flops", C.c_double),
+                ("crops", C.c_int32), ("chains", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -335,7 +336,8 @@ class Handle:
         for i in range(min(cnt.value, cap)):
             s = arr[i]
             out.append({"layer": s.layer.decode(), "kind": s.kind.decode(), "kernel": s.kernel.decode(),
-                        "avg_us": s.avg_us, "alg_bytes": s.alg_bytes, "alg_flops": s.alg_flops})
+                        "avg_us": s.avg_us, "alg_bytes": s.alg_bytes, "alg_flops": s.alg_flops,
+                        "crops": int(s.crops), "chains": int(s.chains)})
         return out
 
     def device_alloc(self, nbytes: int) -> int:

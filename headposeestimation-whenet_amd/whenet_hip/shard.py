@@ -30,6 +30,80 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _parse_cpulist(text: str):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of sysfs `local_cpulist` / `cpulist`)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_numa_cpus(pci_bus_id: str, sysfs_root: str = "/sys"):
+    """(numa_node, cpus) of the PCI device `pci_bus_id` ('0000:c1:00.0') as the kernel reports them:
+    <sysfs>/bus/pci/devices/<id>/numa_node and the node's cpulist (falling back to the device's local_cpulist).
+    numa_node = -1 (no affinity known, e.g. inside most VMs) gives (-1, [])."""
+    import os
+    base = os.path.join(sysfs_root, "bus", "pci", "devices", pci_bus_id.lower())
+    try:
+        with open(os.path.join(base, "numa_node")) as f:
+            node = int(f.read().strip())
+    except (OSError, ValueError):
+        return -1, []
+    if node < 0:
+        return -1, []
+    for path in (os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist"),
+                 os.path.join(base, "local_cpulist")):
+        try:
+            with open(path) as f:
+                cpus = _parse_cpulist(f.read())
+            if cpus:
+                return node, cpus
+        except (OSError, ValueError):
+            continue
+    return node, []
+
+
+def gpu_pci_bus_id(local_rank: int) -> str:
+    """'dddd:bb:dd.0' of HIP device `local_rank` (torch's device properties)."""
+    import torch
+    p = torch.cuda.get_device_properties(local_rank)
+    return f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+
+
+def bind_rank_to_gpu_numa(pci_bus_id: str, index_on_node: int = 0, peers_on_node: int = 1,
+                          sysfs_root: str = "/sys") -> dict:
+    """Pin this process (one rank per GPU) to the CPUs of its GPU's NUMA node, so that the host thread that enqueues
+    the launches and the pinned staging buffers it touches sit next to the GPU's PCIe root.  When `peers_on_node`
+    ranks have their GPUs on the same node, the node's CPUs are divided between them and this rank takes slice
+    `index_on_node`.  Returns what was done (for the bench line); never raises: without NUMA information (node -1,
+    as inside most VMs) the affinity is left as it is."""
+    import os
+    info = {"pci_bus_id": pci_bus_id, "numa_node": -1, "bound": False, "cpus": None}
+    try:
+        node, cpus = gpu_numa_cpus(pci_bus_id, sysfs_root)
+        info["numa_node"] = node
+        if node < 0 or not cpus:
+            return info
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return info
+        peers = max(1, int(peers_on_node))
+        per = max(1, len(allowed) // peers)
+        k = int(index_on_node) % peers
+        mine = allowed[k * per:(k + 1) * per] or allowed
+        os.sched_setaffinity(0, mine)
+        info.update(bound=True, cpus=len(mine), first_cpu=mine[0], last_cpu=mine[-1])
+    except (OSError, AttributeError, ValueError) as e:
+        info["error"] = str(e)[:120]
+    return info
+
+
 def broadcast_bytes(blob: Optional[bytes], src: int = 0, device=None) -> bytes:
     """Broadcast a byte string from rank `src` to every rank of the default process group."""
     import torch

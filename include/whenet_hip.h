@@ -32,8 +32,10 @@ extern "C" {
 #endif
 
 /* 2 (round 3): whenet_op_trunk / whenet_op_stem_dw removed with their kernels; whenet_create_postproc and
- * whenet_op_block_range added; options front_impl, se_fuse, fold12, poison. */
-#define WHENET_ABI_VERSION 2
+ * whenet_op_block_range added; options front_impl, se_fuse, fold12, poison.
+ * 3 (round 4): whenet_launch_stat_t carries the crops and chains of the launch it describes (what whenet_profile
+ * actually ran: with option "inflight" > 1 a forward is ONE chain of the whole batch). */
+#define WHENET_ABI_VERSION 3
 #define WHENET_API __attribute__((visibility("default")))
 
 /* return codes (negative errno-style) */
@@ -81,6 +83,8 @@ typedef struct whenet_launch_stat {
     double  avg_us;             /* mean duration over chains x iterations (HIP events)        */
     double  alg_bytes;          /* algorithmic bytes of this launch: in + out (+skip) once  */
     double  alg_flops;          /* 2 * MACs of this launch                                   */
+    int32_t crops;              /* crops this launch processed (the chain's sub-batch)       */
+    int32_t chains;             /* concurrent sub-batch chains the figures are averaged over */
 } whenet_launch_stat_t;
 
 /* ---- construction: replaces WHENet.__init__ (whenet.py:7-20): graph build +

@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
-"""Expected outputs (float64 oracle, oracle/whenet_oracle.py) for the 48 seeded crops of the f16 accuracy
-contract (tests/test_gpu_parity.py::test_f16_accuracy_contract): 24 scene crops (seed 5) + 24 noise crops (seed 6),
-the seeded synthetic snapshot 1234.  Writes tests/golden/f16_set_expected.npz (angles [48,3], logits [48,252],
-argmax [48,3]).  Usage: python tests/golden/make_f16_set.py"""
+"""Expected outputs of the float64 oracle (oracle/whenet_oracle.py, the seeded synthetic snapshot 1234) for the two
+crop sets of the f16 accuracy contract:
+
+  f16_set_expected.npz      48 crops: 24 scene crops (seed 5) + 24 noise crops (seed 6)
+                            (tests/test_gpu_parity.py::test_f16_accuracy_contract)
+  f16_set512_expected.npz   512 crops: 256 scene crops (seed 41) + 256 noise crops (seed 42)
+                            (::test_f16_error_distribution_512_crops -- round 4: the distribution contract is stated
+                            against the ORACLE, not against the library's own f32 configuration)
+
+Each file: angles [n,3] float64, logits [n,252] float32, argmax [n,3] int32, margins [n,3] float32 (top-2 logit margin
+of each head in the oracle).  Usage: python tests/golden/make_f16_set.py [48|512|all]   (512 crops take ~10 min)"""
 import os
 import sys
 
@@ -14,9 +21,38 @@ sys.path.insert(0, ROOT)
 from oracle import whenet_oracle as O          # noqa: E402
 from whenet_hip import synth, weights as W     # noqa: E402
 
-crops = np.concatenate([synth.scene_crops(24, seed=5), synth.noise_crops(24, seed=6)])
-ref = O.forward(crops, W.synthetic(1234), np.float64)
-out = os.path.join(ROOT, "tests", "golden", "f16_set_expected.npz")
-np.savez_compressed(out, angles=np.stack([ref["yaw"], ref["pitch"], ref["roll"]], 1).astype(np.float64),
-                    logits=ref["logits"].astype(np.float32), argmax=ref["argmax"].astype(np.int32))
-print("wrote", out, os.path.getsize(out), "bytes")
+SETS = {
+    "48": ("f16_set_expected.npz", lambda: np.concatenate([synth.scene_crops(24, seed=5), synth.noise_crops(24, seed=6)])),
+    "512": ("f16_set512_expected.npz",
+            lambda: np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])),
+}
+
+
+def margins(logits):
+    out = []
+    for lo, hi in ((0, 120), (120, 186), (186, 252)):
+        s = np.sort(logits[:, lo:hi], axis=1)
+        out.append(s[:, -1] - s[:, -2])
+    return np.stack(out, 1).astype(np.float32)
+
+
+def make(which):
+    name, gen = SETS[which]
+    crops = gen()
+    w = W.synthetic(1234)
+    parts = []
+    for lo in range(0, crops.shape[0], 16):                    # (chunks: the float64 intermediates of 16 crops are ~1 GB)
+        parts.append(O.forward(crops[lo:lo + 16], w, np.float64))
+        print(f"  {which}: {min(lo + 16, crops.shape[0])} / {crops.shape[0]}", flush=True)
+    cat = {k: np.concatenate([p[k] for p in parts]) for k in ("yaw", "pitch", "roll", "logits", "argmax")}
+    out = os.path.join(ROOT, "tests", "golden", name)
+    np.savez_compressed(out, angles=np.stack([cat["yaw"], cat["pitch"], cat["roll"]], 1).astype(np.float64),
+                        logits=cat["logits"].astype(np.float32), argmax=cat["argmax"].astype(np.int32),
+                        margins=margins(cat["logits"].astype(np.float64)))
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    arg = sys.argv[1] if len(sys.argv) > 1 else "48"
+    for which in (("48", "512") if arg == "all" else (arg,)):
+        make(which)

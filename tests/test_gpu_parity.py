@@ -9,8 +9,11 @@ Tolerances (stated here, per dtype):
        over 1536 angles (512 crops) mean 0.048, p95 0.21, p99 0.47, max 1.2 deg, and WHICH angle is the outlier
        changes with every change of a rounding point (round 2's own error study, profiles/r02/f16_error_study.txt,
        has maxima from 0.42 to 0.90 deg on the same 48 crops across rounding subsets).  So the contract is stated on
-       the distribution (test_f16_accuracy_contract, test_f16_error_distribution_512_crops: mean / p95 / p99 / bin
-       flips), and every single angle checked anywhere is within F16_DEG = 1.5 deg = half a 3-degree bin;
+       the distribution AGAINST THE FLOAT64 ORACLE (test_f16_accuracy_contract: 48 crops; round 4:
+       test_f16_error_distribution_512_crops: 512 crops against tests/golden/f16_set512_expected.npz, not against the
+       library's own f32 path): mean / p95 / p99 / p99.9 / bin flips; every single f16 angle of the small sets (golden
+       crops, 48-crop set, batch tests) is within F16_DEG = 1.0 deg, and the 512-crop set's maximum -- the tail of 1536
+       draws -- within F16_DEG_TAIL = 1.5 deg = half a 3-degree bin;
        per-kernel tensors <= 1.5e-2 * scale (each kernel alone, fed oracle inputs rounded to f16);
        bin argmax: asserted on EVERY golden crop -- equal, or the oracle's top-2
        margin is below the measured logit error (the synthetic heads are 3-bin-wide Gaussian bumps:
@@ -28,7 +31,8 @@ from whenet_hip import _lib, spec, synth, weights as W
 pytestmark = pytest.mark.gpu
 
 F32_DEG = 1e-3
-F16_DEG = 1.5
+F16_DEG = 1.0              # every f16 angle of the small sets; round 3 had widened this to 1.5 for all sets
+F16_DEG_TAIL = 1.5         # the maximum over the 512-crop set only (1536 draws of the noise's tail; p99.9 is bounded below it)
 F16_ARGMAX_FLIPS = 3
 MARGIN_F32 = 2e-3
 DTYPES = [("f32", _lib.F32), ("f16", _lib.F16)]
@@ -632,51 +636,71 @@ def test_front_impl_variants_end_to_end(blob, golden):
             h.set_option("front_impl", 3)
 
 
+def _flips_are_runner_ups(am, lg, fx_logits, fx_argmax):
+    """every bin flip goes to the oracle's runner-up of a head whose top-2 margin is below twice THIS crop's logit error"""
+    flips = np.argwhere(am != fx_argmax)
+    lo = {0: 0, 1: 120, 2: 186}
+    nb = {0: 120, 1: 66, 2: 66}
+    for i, hd in flips:
+        ref = fx_logits[i, lo[hd]:lo[hd] + nb[hd]]
+        order = np.argsort(ref)
+        noise = float(np.abs(lg[i] - fx_logits[i]).max())
+        assert ref[order[-1]] - ref[order[-2]] <= 2 * noise and am[i, hd] == int(order[-2]), (i, hd, noise)
+    return flips
+
+
 def test_f16_accuracy_contract(blob):
     """The f16 product's error against the float64 oracle on 48 seeded crops that are NOT the golden crops
     (tests/golden/f16_set_expected.npz, generated by tests/golden/make_f16_set.py from oracle/whenet_oracle.py;
-    round 2 measured max 0.63 deg, p95 0.23 deg, 1 bin flip of 144 on this set): max <= 0.7 deg, p95 <= 0.25 deg,
-    at most 2 bin flips, each to the oracle's runner-up bin under the measured logit noise."""
+    measured: round 2 max 0.63 / p95 0.23 deg, round 3's default schedule max 0.87 / p95 0.23 deg, 0-1 bin flips of
+    144): mean <= 0.065 deg, p95 <= 0.25 deg, max <= 1.0 deg (= F16_DEG), at most 2 bin flips, each to the oracle's
+    runner-up bin under the crop's own logit error."""
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set_expected.npz"))
     crops = np.concatenate([synth.scene_crops(24, seed=5), synth.noise_crops(24, seed=6)])
     with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
         ypr, am, lg = h.forward(crops)
     e = np.abs(ypr - fx["angles"])
     noise = float(np.abs(lg - fx["logits"]).max())
-    flips = np.argwhere(am != fx["argmax"])
+    flips = _flips_are_runner_ups(am, lg, fx["logits"], fx["argmax"])
     print(f"\n[f16, 48 crops] max {e.max():.4f} mean {e.mean():.5f} p95 {np.percentile(e, 95):.4f} deg; "
           f"{len(flips)} bin flips of {am.size}; max |logit err| {noise:.4f}")
-    assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.25 and e.max() <= 1.0
+    assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.25 and e.max() <= F16_DEG
     assert len(flips) <= 2, flips
-    lo = {0: 0, 1: 120, 2: 186}
-    nb = {0: 120, 1: 66, 2: 66}
-    for i, hd in flips:
-        ref = fx["logits"][i, lo[hd]:lo[hd] + nb[hd]]
-        order = np.argsort(ref)
-        assert ref[order[-1]] - ref[order[-2]] <= 2 * noise and am[i, hd] == int(order[-2]), (i, hd)
     with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
         y32, a32, _ = h.forward(crops)
     assert np.abs(y32 - fx["angles"]).max() <= F32_DEG
 
 
 def test_f16_error_distribution_512_crops(blob):
-    """The f16 error as a distribution: 512 seeded crops (1536 angles) against the f32 configuration of the same
-    library (itself within 1e-3 deg of the oracle), for the default schedule and without option fold12.  Measured
-    (tools/f16_error_gpu.py): default mean 0.048 / p95 0.21 / p99 0.47 / max 1.21 deg, 12 bin flips of 1536;
-    fold12=0 mean 0.055 / p95 0.24 / p99 0.52 / max 1.39, 10 flips."""
+    """The f16 error as a distribution, pinned to the ORACLE: 512 seeded crops (1536 angles) against the float64
+    oracle's angles / logits / argmax (tests/golden/f16_set512_expected.npz, make_f16_set.py 512), for the default
+    schedule and without option fold12.  The f32 configuration is held to the north-star bar on the same 512 crops
+    (<= 1e-3 deg, argmax equal wherever the oracle's top-2 margin exceeds float32 round-off).
+    Bounds (measured values: profiles/r04/f16_error_gpu.txt): mean <= 0.065, p95 <= 0.28, p99 <= 0.60, p99.9 <= 1.25,
+    max <= F16_DEG_TAIL = 1.5 deg; <= 24 bin flips of 1536, every one of them to the oracle's runner-up bin of a head
+    whose top-2 margin is below twice that crop's own logit error."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set512_expected.npz"))
     crops = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])
     with _lib.Handle(blob, device=0, dtype=_lib.F32) as h32:
         y32, a32, l32 = h32.forward(crops)
+    e32 = np.abs(y32 - fx["angles"])
+    safe = fx["margins"] > MARGIN_F32
+    print(f"\n[f32, 512 crops vs oracle] max {e32.max():.2e} deg; max |logit err| {np.abs(l32 - fx['logits']).max():.2e}; "
+          f"{int((~safe).sum())} heads under the {MARGIN_F32} margin")
+    assert e32.max() <= F32_DEG and safe.mean() > 0.98
+    assert np.array_equal(a32[safe], fx["argmax"][safe])
     for fold in (1, 0):
         with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
             h.set_option("fold12", fold)
             y, a, l = h.forward(crops)
-        e = np.abs(y - y32)
-        flips = int((a != a32).sum())
-        print(f"\n[f16 fold12={fold}, 512 crops vs f32] mean {e.mean():.4f} p95 {np.percentile(e, 95):.4f} "
-              f"p99 {np.percentile(e, 99):.4f} max {e.max():.4f} deg; {flips} bin flips of {a.size}")
-        assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.28 and np.percentile(e, 99) <= 0.60 and e.max() <= F16_DEG
-        assert flips <= 24                                   # 1.5 % of the bins (near ties of neighbouring bins)
+        e = np.abs(y - fx["angles"])
+        flips = _flips_are_runner_ups(a, l, fx["logits"], fx["argmax"])
+        print(f"[f16 fold12={fold}, 512 crops vs oracle] mean {e.mean():.4f} p95 {np.percentile(e, 95):.4f} "
+              f"p99 {np.percentile(e, 99):.4f} p99.9 {np.percentile(e, 99.9):.4f} max {e.max():.4f} deg; "
+              f"{len(flips)} bin flips of {a.size}")
+        assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.28 and np.percentile(e, 99) <= 0.60
+        assert np.percentile(e, 99.9) <= 1.25 and e.max() <= F16_DEG_TAIL
+        assert len(flips) <= 24                              # 1.5 % of the bins (near ties of neighbouring bins)
 
 
 def test_no_kernel_reads_what_the_forward_did_not_write(handle):

@@ -157,6 +157,15 @@ def test_f16_set_fixture_is_the_oracle(weights):
     assert np.allclose(ref["logits"], fx["logits"][idx], rtol=1e-6, atol=1e-5)          # (stored as float32)
     assert np.array_equal(ref["argmax"], fx["argmax"][idx])
     assert fx["angles"].shape == (48, 3) and fx["logits"].shape == (48, 252)
+    # round 4: the 512-crop set of the f16 DISTRIBUTION contract is the oracle's too (it used to be the f32 HIP path)
+    fx5 = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set512_expected.npz"))
+    big = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])
+    idx5 = [0, 255, 256, 511]
+    ref5 = O.forward(big[idx5], weights, np.float64)
+    assert np.abs(np.stack([ref5["yaw"], ref5["pitch"], ref5["roll"]], 1) - fx5["angles"][idx5]).max() < 1e-9
+    assert np.allclose(ref5["logits"], fx5["logits"][idx5], rtol=1e-6, atol=1e-5)
+    assert np.array_equal(ref5["argmax"], fx5["argmax"][idx5])
+    assert fx5["angles"].shape == (512, 3) and fx5["margins"].shape == (512, 3) and (fx5["margins"] >= 0).all()
 
 
 def test_block1_project_composed_with_block2_expand_is_the_same_function(weights, golden):

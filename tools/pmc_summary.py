@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSVs (one directory per pass, prefix + 1..N) per kernel NAME: averages
 over every dispatch of the run (the timed region and the profile pass launch the same sub-batch
-geometry).  usage: pmc_summary.py gpurun_out/pmc_f16_b64_p [traffic.json]"""
+geometry).  usage: pmc_summary.py gpurun_out/pmc_f16_b64_c64_p [traffic.json crops_per_launch]
+The traffic JSON holds one set per crops-per-launch ("by_crops_per_launch"): an existing file is updated, not replaced."""
 import csv
 import glob
 import json
+import os
 import re
 import subprocess
 import sys
@@ -90,6 +92,8 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"]):
               "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
               "valu_active_pct_of_wave_cycles": 100 * avg(a, "SQ_ACTIVE_INST_VALU") / wc,
               "valu_insts_per_wave": avg(a, "SQ_INSTS_VALU") / waves,
+              "wait_pct_of_wave_cycles": 100 * avg(a, "SQ_WAIT_ANY") / wc,
+              "l2_hit_pct": 100 * hit / ((hit + miss) or 1),
               "mfma_busy_pct_of_cu_cycles": (100 * mfma_busy / (4 * busy_cu)) if busy_cu else None,
               "lds_bank_conflict_pct": 100 * avg(a, "SQ_LDS_BANK_CONFLICT") / (avg(a, "SQ_ACTIVE_INST_LDS") or 1)}
 # Matrix-core occupancy per kernel (pass 6).  SQ_VALU_MFMA_BUSY_CYCLES counts cycles a SIMD's MFMA pipe is
@@ -101,7 +105,20 @@ if any(r[2] for r in mfma_rows):
     for k, us, mb, mops, im, bc, gui in mfma_rows:
         print(f"{k:52s}{us:7.1f} {mb:11.0f} {mops:10.0f} {im:10.0f} {bc:11.0f} {100 * mb / (4 * bc) if bc else 0:12.2f}")
 if len(sys.argv) > 2:
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 "
-                       "(MI355X_MICROARCH.md HBM section: 64 B tallied per 128-B request on 16-B/lane streams; consistent "
-                       "here with the known read volumes of the expand and depthwise kernels); averages per dispatch",
-               "kernels": out}, open(sys.argv[2], "w"), indent=1)
+    cpl = str(int(sys.argv[3])) if len(sys.argv) > 3 else None
+    if cpl is None:
+        raise SystemExit("pmc_summary.py: the traffic JSON needs the crops per launch of the profiled chain (third argument)")
+    blob = {}
+    if os.path.exists(sys.argv[2]):
+        try:
+            blob = json.load(open(sys.argv[2]))
+        except ValueError:
+            blob = {}
+    if "by_crops_per_launch" not in blob:
+        blob = {"by_crops_per_launch": {}}
+    blob["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB -> bytes, FETCH_SIZE x2 "
+                    "(MI355X_MICROARCH.md HBM section: 64 B tallied per 128-B request on 16-B/lane streams; consistent "
+                    "here with the known read volumes of the expand and depthwise kernels); averages per dispatch; one "
+                    "set per crops-per-launch of the profiled chain (ONE chain alone on the GPU: tools/pmc_round.sh)")
+    blob["by_crops_per_launch"][cpl] = {"crops_per_launch": int(cpl), "source": prefix, "kernels": out}
+    json.dump(blob, open(sys.argv[2], "w"), indent=1)

@@ -36,14 +36,13 @@ int main(int argc, char** argv) {
     for (const Shape& sh : shapes)
     for (int thr : {256, 512, 1024}) {
         using T = half_t;
-        setenv("WHENET_FRONT_THREADS", std::to_string(thr).c_str(), 1);
         const int Ho = ceil_div(sh.H, sh.s);
         const int padt = std::max((Ho - 1) * sh.s + sh.k - sh.H, 0);
         FrontArgs a{};
         a.k = sh.k; a.s = sh.s; a.H = sh.H; a.Ho = Ho; a.Cin = sh.Cin; a.Cexp = sh.Cexp; a.pad = padt / 2; a.n = n;
         a.KSe = ceil_div(sh.Cin, 16); a.NTe = ceil_div(sh.Cexp, 32);
         a.plan = plan_front(WHENET_F16, sh.k, sh.s, sh.H, Ho, sh.Cexp);
-        a.plan.threads = front_threads(a.plan, n);
+        a.plan.threads = thr;
         a.x = dalloc<T>(size_t(n) * sh.H * sh.H * sh.Cin, 1.f);
         a.wep = dalloc<T>(size_t(a.KSe) * a.NTe * 64 * 8, 0.05f);
         a.be = dalloc<float>(a.NTe * 32, 0.1f);
