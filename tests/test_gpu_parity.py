@@ -676,7 +676,8 @@ def test_f16_error_distribution_512_crops(blob):
     oracle's angles / logits / argmax (tests/golden/f16_set512_expected.npz, make_f16_set.py 512), for the default
     schedule and without option fold12.  The f32 configuration is held to the north-star bar on the same 512 crops
     (<= 1e-3 deg, argmax equal wherever the oracle's top-2 margin exceeds float32 round-off).
-    Bounds (measured values: profiles/r04/f16_error_gpu.txt): mean <= 0.065, p95 <= 0.28, p99 <= 0.60, p99.9 <= 1.25,
+    Bounds (measured, profiles/r04/f16_error_gpu.txt: default mean 0.048 / p95 0.21 / p99 0.47 / p99.9 0.79 / max 1.21 deg, 12 flips;
+    fold12=0 mean 0.055 / p95 0.24 / p99 0.52 / p99.9 1.00 / max 1.39 deg, 10 flips): mean <= 0.065, p95 <= 0.28, p99 <= 0.60, p99.9 <= 1.1,
     max <= F16_DEG_TAIL = 1.5 deg; <= 24 bin flips of 1536, every one of them to the oracle's runner-up bin of a head
     whose top-2 margin is below twice that crop's own logit error."""
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set512_expected.npz"))
@@ -687,7 +688,7 @@ def test_f16_error_distribution_512_crops(blob):
     safe = fx["margins"] > MARGIN_F32
     print(f"\n[f32, 512 crops vs oracle] max {e32.max():.2e} deg; max |logit err| {np.abs(l32 - fx['logits']).max():.2e}; "
           f"{int((~safe).sum())} heads under the {MARGIN_F32} margin")
-    assert e32.max() <= F32_DEG and safe.mean() > 0.98
+    assert e32.max() <= F32_DEG and safe.mean() > 0.97          # (31 of 1536 heads are closer than float32 round-off)
     assert np.array_equal(a32[safe], fx["argmax"][safe])
     for fold in (1, 0):
         with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
@@ -699,7 +700,7 @@ def test_f16_error_distribution_512_crops(blob):
               f"p99 {np.percentile(e, 99):.4f} p99.9 {np.percentile(e, 99.9):.4f} max {e.max():.4f} deg; "
               f"{len(flips)} bin flips of {a.size}")
         assert e.mean() <= 0.065 and np.percentile(e, 95) <= 0.28 and np.percentile(e, 99) <= 0.60
-        assert np.percentile(e, 99.9) <= 1.25 and e.max() <= F16_DEG_TAIL
+        assert np.percentile(e, 99.9) <= 1.1 and e.max() <= F16_DEG_TAIL
         assert len(flips) <= 24                              # 1.5 % of the bins (near ties of neighbouring bins)
 
 
