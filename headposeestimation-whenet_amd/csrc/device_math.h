@@ -28,6 +28,28 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// LDS traffic of ONE wave, ordered for its other lanes (DS operations of a wave execute in order; this only keeps the
+// compiler from moving them and waits for the data)
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// Swish of two values with packed f32 arithmetic: v_pk_add_f32 / v_pk_mul_f32 for the three plain steps, the two
+// quarter-rate transcendentals per value (v_exp_f32, v_rcp_f32) unpacked: 3.5 instructions per value instead of 5.5.
+// Same operations in the same order as swish_f<false> (x * rcp(1 + exp2(-x * log2(e)))): same bits.
+__device__ __forceinline__ float2v swish2(float2v x) {
+    const float2v t = x * float2v{-1.4426950408889634f, -1.4426950408889634f};
+    const float2v d = float2v{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + float2v{1.0f, 1.0f};
+    return x * float2v{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
+__device__ __forceinline__ float quad_xor1(float v) {      // DPP quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {      // DPP quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
 template <typename T> struct IsF32 { static constexpr bool value = false; };
 template <> struct IsF32<float> { static constexpr bool value = true; };
 

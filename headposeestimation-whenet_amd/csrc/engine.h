@@ -26,6 +26,7 @@ struct DevDw {
     float* w = nullptr;
     float* bias = nullptr;
     half_t* wt = nullptr;      // f16: Toeplitz operand image of the kernel for front2.hip (pack_dw_toeplitz)
+    half_t* wt7 = nullptr;     // f16, 7 x 7 blocks: the image front7.hip reads (group-aligned: xs = 4 - k / 2)
     DwPlan plan;
 };
 struct DevSe {
@@ -40,6 +41,8 @@ struct DevBlock {
     FrontPlan fplan;       // fused expand+depthwise tiling (blocks with an expand conv)
     Front2Plan f2plan;     // f16: the same stage with the taps on the matrix cores (front2.hip)
     bool f2_preferred = false;
+    bool f7_supported = false; // f16: the block's shape has a front7.hip kernel (7 x 7 maps, blocks 13-16)
+    int f7_chunks = 1;         // channel chunks of its plans (the same for every group size: see front7_plan_for)
     DevSe se;
     DevPw project;
 };
@@ -143,7 +146,7 @@ class Engine {
     void* enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec);
     bool fold12_active() const;
     struct BlockSchedule {     // which kernels a block runs under the current options
-        bool fused = false, use_f2 = false, se_in_front = false, se_fused = false;
+        bool fused = false, use_f2 = false, use_f7 = false, se_in_front = false, se_fused = false;
         int se_ntiles = 1, se_chunks = 1;
     };
     BlockSchedule block_schedule(const DevBlock& b) const;
@@ -173,6 +176,8 @@ class Engine {
     int front_impl_ = 1;        // option "front_impl": 0 = front.hip everywhere, 1 = per layer (f16: front2.hip where it is
                                 // the faster kernel), 2 = front2.hip everywhere (f16)
     bool poison_ = false;       // debug option "poison": NaN-fill the activation arena before every forward
+    bool front7_ = true;        // option "front7": blocks 13-16 of an f16 handle run front7.hip (a group of crops per workgroup)
+                                // when front_impl = 1; 0 = the per-layer choice of round 3 (front.hip there)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster
                                 // front kernels a third chain only adds contention: 100.1 k vs 97.2 k crops/s at batch 64,

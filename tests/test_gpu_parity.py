@@ -157,6 +157,43 @@ def test_mbconv_block_kernels(handle, taps, index):
         assert rel_err(r["out"], taps[f"{p}/out"]) < 3 * t, "out"
 
 
+def test_front7_group_kernel(blob, taps, golden):
+    """Round 4: blocks 13-16 (7 x 7 maps) of an f16 handle run front7.hip -- a group of crops per workgroup (2 crops up to 16
+    crops per launch, 4 above), the chunk's expand weights staged once in LDS.  Each block on the oracle's own input:
+    within the kernel tolerance of the oracle and of round 3's kernel (option front7=0); and the group size changes no
+    bit: crops travel through launches of 1, 2, 3, 16, 17 and 21 crops (tail groups of both sizes) with identical results."""
+    t = 1.5e-2
+    with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+        for index in (13, 14, 15, 16):
+            x = taps[f"b{index - 1}/out"].astype(np.float32)
+            h.set_option("se_fuse", 0)
+            r7 = h.op_block(index, x)
+            h.set_option("front7", 0)
+            r3 = h.op_block(index, x)
+            h.set_option("front7", 1)
+            h.set_option("se_fuse", 1)
+            assert not np.array_equal(r7["dw"], r3["dw"]), "front7 is not active"
+            assert rel_err(r7["dw"], r3["dw"]) < t and rel_err(r7["gate"], r3["gate"]) < 2 * t and rel_err(r7["out"], r3["out"]) < 3 * t
+            assert rel_err(r7["dw"], taps[f"b{index}/dw"]) < 2 * t and rel_err(r7["out"], taps[f"b{index}/out"]) < 3 * t
+            # the same block on a ragged batch: 21 copies + permutation -> every crop bitwise what it is alone
+            xs = np.concatenate([x] * 11)[:21]
+            big = h.op_block(index, xs)
+            for i in range(21):
+                assert np.array_equal(big["out"][i], r7_like(h, index, xs[i:i + 1])), (index, i)
+        crops = np.concatenate([golden["crops"], synth.scene_crops(13, seed=77)])          # 21 crops
+        y21, a21, l21 = h.forward(crops)
+        for lo, hi in ((0, 1), (1, 3), (3, 6), (0, 16), (4, 21), (20, 21)):
+            y, a, l = h.forward(crops[lo:hi])
+            assert np.array_equal(l, l21[lo:hi]) and np.array_equal(y, y21[lo:hi]), (lo, hi)
+        h.set_option("front7", 0)
+        y0, a0, l0 = h.forward(crops)
+        assert not np.array_equal(l0, l21) and np.abs(l0 - l21).max() < 0.5
+
+
+def r7_like(h, index, x1):
+    return h.op_block(index, x1)["out"][0]
+
+
 def test_block1_project_folded_into_block2_expand(handle, taps):
     """Option fold12 (f16): block 2's front kernel reads block 1's gated depthwise output through the composed
     project1 x expand2 weights (snapshot.cpp).  The two-step form of the same range is bitwise the per-block operators
