@@ -21,6 +21,21 @@ __device__ __forceinline__ float swish_f(float x) {
     return x * sigmoid_f<PRECISE>(x);
 }
 
+// Swish of the convolution epilogues (7.2 M evaluations per crop).  Round 4: the f32 configuration uses the hardware forms
+// here too -- x * v_rcp_f32(1 + v_exp_f32(-x * log2(e))), 5 instructions -- instead of libm's expf and an IEEE division
+// (~25 instructions per value: the f32 fused kernels spent most of their VALU time there).  v_exp_f32 / v_rcp_f32 are 1-ulp
+// operations and the rounded product x * log2(e) moves the result by <= |x| * 4e-8 relative: a few ulp, below the
+// summation noise of the K-deep f32 dot products in front of it (measured: profiles/r04/f32_swish.txt -- the angle error
+// against the float64 oracle is unchanged).  The squeeze-excite gates (sigmoid_f<true>, 1152 values per crop) keep the
+// precise forms.  -DWHENET_PRECISE_CONV_SWISH=1 restores round 3's arithmetic.
+#ifndef WHENET_PRECISE_CONV_SWISH
+#define WHENET_PRECISE_CONV_SWISH 0
+#endif
+template <typename T>
+__device__ __forceinline__ float conv_swish(float x) {
+    return swish_f<(WHENET_PRECISE_CONV_SWISH != 0) && sizeof(T) == 4>(x);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
 // loads and stores (s_waitcnt vmcnt(0)), which would stall prefetched operands and output stores
 // at every phase boundary; the kernels that use this barrier exchange data through LDS only.

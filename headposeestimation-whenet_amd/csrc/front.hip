@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                 if (cur.tl * 32 + 8 * qq < ccur) {          // (wave-uniform: chunk widths are multiples of 8)
                     OT o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = T(swish_f<IsF32<T>::value>(acc[4 * qq + r] + bv[qq][r]));
+                    for (int r = 0; r < 4; ++r) o[r] = T(conv_swish<T>(acc[4 * qq + r] + bv[qq][r]));
                     *reinterpret_cast<OT*>(epix + nl * SZ) = o;
                 }
             }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
             VCT o;
 #pragma unroll
             for (int v = 0; v < VC; ++v) {
-                const float y = swish_f<IsF32<T>::value>(acc[p][v] + bs[v]);
+                const float y = conv_swish<T>(acc[p][v] + bs[v]);
                 sum[v] += y;
                 o[v] = T(y);
             }

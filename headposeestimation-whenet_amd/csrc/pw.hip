@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float y = sum[4 * i4 + r] + bv[i4][r];
-            if constexpr (ACT == ACT_SWISH) y = swish_f<IsF32<T>::value>(y);
+            if constexpr (ACT == ACT_SWISH) y = conv_swish<T>(y);
             if constexpr (RES) y += float(rv[i4][r]);
             o[r] = T(y);
         }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = acc[t < NT ? t : 0][4 * qq + r] + bv[r];
-                            if constexpr (ACT == ACT_SWISH) v = swish_f<IsF32<T>::value>(v);
+                            if constexpr (ACT == ACT_SWISH) v = conv_swish<T>(v);
                             y[r] = v;
                         }
                     } else {
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float y = acc[r] + bias[n0 + r];
-        if constexpr (ACT == ACT_SWISH) y = swish_f<IsF32<T>::value>(y);
+        if constexpr (ACT == ACT_SWISH) y = conv_swish<T>(y);
         if constexpr (RES) y += float(res[size_t(m) * N + n0 + r]);
         out[size_t(m) * N + n0 + r] = T(y);
     }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void whenet_stem_kernel(const uint8_t* __restr
     for (int g = 0; g < STEM_C / V; ++g) {
         float y[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) y[i] = swish_f<IsF32<T>::value>(acc[g * V + i] + bias[g * V + i]);
+        for (int i = 0; i < V; ++i) y[i] = conv_swish<T>(acc[g * V + i] + bias[g * V + i]);
         dst[g] = float_to_vec<T>(y);
     }
 }

@@ -674,15 +674,16 @@ def test_front_impl_variants_end_to_end(blob, golden):
 
 
 def _flips_are_runner_ups(am, lg, fx_logits, fx_argmax):
-    """every bin flip goes to the oracle's runner-up of a head whose top-2 margin is below twice THIS crop's logit error"""
+    """every bin flip goes to a bin whose ORACLE logit is within twice THIS crop's logit error of the oracle's maximum (a
+    near tie that the f16 noise may legitimately resolve the other way: usually the runner-up, for a bimodal head another
+    mode)"""
     flips = np.argwhere(am != fx_argmax)
     lo = {0: 0, 1: 120, 2: 186}
     nb = {0: 120, 1: 66, 2: 66}
     for i, hd in flips:
         ref = fx_logits[i, lo[hd]:lo[hd] + nb[hd]]
-        order = np.argsort(ref)
         noise = float(np.abs(lg[i] - fx_logits[i]).max())
-        assert ref[order[-1]] - ref[order[-2]] <= 2 * noise and am[i, hd] == int(order[-2]), (i, hd, noise)
+        assert ref.max() - ref[am[i, hd]] <= 2 * noise, (i, hd, noise, float(ref.max() - ref[am[i, hd]]))
     return flips
 
 
@@ -690,8 +691,8 @@ def test_f16_accuracy_contract(blob):
     """The f16 product's error against the float64 oracle on 48 seeded crops that are NOT the golden crops
     (tests/golden/f16_set_expected.npz, generated by tests/golden/make_f16_set.py from oracle/whenet_oracle.py;
     measured: round 2 max 0.63 / p95 0.23 deg, round 3's default schedule max 0.87 / p95 0.23 deg, 0-1 bin flips of
-    144): mean <= 0.065 deg, p95 <= 0.25 deg, max <= 1.0 deg (= F16_DEG), at most 2 bin flips, each to the oracle's
-    runner-up bin under the crop's own logit error."""
+    144): mean <= 0.065 deg, p95 <= 0.25 deg, max <= 1.0 deg (= F16_DEG), at most 2 bin flips, each to a bin within
+    twice the crop's own logit error of the oracle's maximum."""
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set_expected.npz"))
     crops = np.concatenate([synth.scene_crops(24, seed=5), synth.noise_crops(24, seed=6)])
     with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
@@ -715,8 +716,8 @@ def test_f16_error_distribution_512_crops(blob):
     (<= 1e-3 deg, argmax equal wherever the oracle's top-2 margin exceeds float32 round-off).
     Bounds (measured, profiles/r04/f16_error_gpu.txt: default mean 0.048 / p95 0.21 / p99 0.47 / p99.9 0.79 / max 1.21 deg, 12 flips;
     fold12=0 mean 0.055 / p95 0.24 / p99 0.52 / p99.9 1.00 / max 1.39 deg, 10 flips): mean <= 0.065, p95 <= 0.28, p99 <= 0.60, p99.9 <= 1.1,
-    max <= F16_DEG_TAIL = 1.5 deg; <= 24 bin flips of 1536, every one of them to the oracle's runner-up bin of a head
-    whose top-2 margin is below twice that crop's own logit error."""
+    max <= F16_DEG_TAIL = 1.5 deg; <= 24 bin flips of 1536, every one of them to a bin whose oracle logit is within
+    twice that crop's own logit error of the oracle's maximum."""
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f16_set512_expected.npz"))
     crops = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])
     with _lib.Handle(blob, device=0, dtype=_lib.F32) as h32:
