@@ -85,13 +85,13 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
                 partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f2plan.ntiles()) * b.dw.C);
                 partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f2plan.ntiles()) * size_t(b.f2plan.chunks) *
                                                                     size_t(se_padded_r(b.se.R)));
-                // the 7 x 7 blocks: a group of crops per workgroup (front7.hip); its Toeplitz image is group-aligned
-                b.f7_supported = front7_supported(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.cin);
-                if (b.f7_supported) {
-                    b.dw.wt7 = upload(pack_dw_toeplitz(hb.dw.w, hb.spec.k, 1, hb.dw.C, 4 - hb.spec.k / 2));
-                    b.f7_chunks = front7_plan_for(hb.spec.cin, hb.dw.C, 64).chunks;
-                    partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f7_chunks) * size_t(se_padded_r(b.se.R)));
-                }
+            }
+            // the 7 x 7 blocks, both dtypes: a group of crops per workgroup (front7.hip); f16: its Toeplitz image is group-aligned
+            b.f7_supported = front7_supported(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.cin);
+            if (b.f7_supported) {
+                if (dtype_ == WHENET_F16) b.dw.wt7 = upload(pack_dw_toeplitz(hb.dw.w, hb.spec.k, 1, hb.dw.C, 4 - hb.spec.k / 2));
+                b.f7_chunks = front7_plan_for(dtype_, hb.spec.cin, hb.dw.C, 64).chunks;
+                partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f7_chunks) * size_t(se_padded_r(b.se.R)));
             }
         }
         blocks_.push_back(b);
@@ -364,7 +364,7 @@ struct Rec {
 Engine::BlockSchedule Engine::block_schedule(const DevBlock& b) const {
     BlockSchedule r;
     r.fused = fuse_front_ && b.spec.has_expand() && pw_impl_ == 0;
-    r.use_f7 = r.fused && dtype_ == WHENET_F16 && front_impl_ == 1 && front7_ && b.f7_supported;
+    r.use_f7 = r.fused && front_impl_ == 1 && front7_ && b.f7_supported;
     r.use_f2 = r.fused && !r.use_f7 && dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
     r.se_in_front = r.fused;                 // the front kernels apply the SE reduce conv to their channel sums
     r.se_ntiles = r.use_f7 ? 1 : (r.use_f2 ? b.f2plan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles()));
@@ -406,10 +406,11 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
                    "fold12: block outside the folded pair");
     if (bs.use_f7) {
         Front7Args a{};
+        a.dtype = dtype_;
         a.x = in;
         a.wep = b.expand.wp;
         a.be = b.expand.bias;
-        a.wdt = b.dw.wt7;
+        a.wdt = dtype_ == WHENET_F16 ? static_cast<const void*>(b.dw.wt7) : static_cast<const void*>(b.dw.w);
         a.bd = b.dw.bias;
         a.out = v.d;
         a.rpart = v.partial;
@@ -420,8 +421,8 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.Cexp = cexp;
         a.NTe = b.expand.NTILES;
         a.n = n;
-        a.plan = front7_plan_for(sp.cin, cexp, n);
-        R(p + "/front", "front", kernel_name_front7(sp.k, a.plan).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
+        a.plan = front7_plan_for(dtype_, sp.cin, cexp, n);
+        R(p + "/front", "front", kernel_name_front7(dtype_, sp.k, a.plan).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front7(a, s); });
     } else if (use_f2) {
         Front2Args a{};

@@ -35,6 +35,7 @@
 
 #include <atomic>
 #include <string>
+#include <type_traits>
 
 namespace whenet {
 
@@ -43,12 +44,13 @@ namespace {
 constexpr int HW7 = 7;                 // the map is 7 x 7
 
 struct F7Params {
-    const half_t* x;                   // [n][49][Cin]
-    const half_t* wep;                 // packed expand weights (MFMA fragment order, snapshot.h)
+    const void* x;                     // [n][49][Cin] T
+    const void* wep;                   // packed expand weights (MFMA fragment order, snapshot.h)
     const float* be;                   // [Cexp]
-    const half_t* wdt;                 // pack_dw_toeplitz(w, k, 1, C, xs = 4 - k / 2) image: 3 chunks per (block, ky)
+    const void* wdt;                   // f16: pack_dw_toeplitz(w, k, 1, C, xs = 4 - k / 2) image, 3 chunks per (block, ky);
+                                       // f32: the depthwise kernel itself, [k*k][Cexp] floats
     const float* bd;                   // [Cexp]
-    half_t* out;                       // [n][49][Cexp]
+    void* out;                         // [n][49][Cexp] T
     float* rpart;                      // [n][chunks][RPse]: this workgroup's share of the SE reduce conv, per crop
     const float* w1t;                  // [R][Cexp]
     int n, Cin, Cexp, NTe, R, RPse;
@@ -109,7 +111,11 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
     };
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
     half8 a[KS];
-    int strip = wave;
+    // few strips (groups of 2 crops: 4 strips x NT tiles <= the waves): one (strip, tile) task per wave instead of one strip
+    // per wave over all tiles -- at small launches the expand phase is the workgroup's critical path
+    constexpr bool SPLIT = nstrip * NT <= NWAVE;
+    int strip = SPLIT ? (wave < nstrip * NT ? wave % nstrip : nstrip) : wave;
+    const int t_lo = SPLIT ? wave / nstrip : 0, t_hi = SPLIT ? t_lo + 1 : NT;
     if (strip < nstrip) {
         const unsigned off = a_offset(strip);
 #pragma unroll
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
         const bool more = strip + NWAVE < nstrip;              // (uniform)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (t < t_lo || t >= t_hi) continue;               // (uniform)
             float16v acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -308,21 +315,256 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
     STAMP(6);
 }
 
+// ---- the f32 (parity) configuration of the same kernel --------------------------------------------------------------------
+// Same decomposition; what differs is the arithmetic the f32 path owes the 1e-3 degree bar:
+//   * expand on v_mfma_f32_32x32x2_f32 (exact f32, an fmaf chain in k order -- the same instruction sequence as pw.hip /
+//     front.hip with the operand roles swapped, so the expanded values have the same bits), 24 k-steps of 8: at 64 FLOP per
+//     cycle and SIMD this phase IS the kernel (2 tasks of 96 MFMAs per wave, two waves per SIMD: ~10 us per workgroup) --
+//     the f32 kernel is matrix-pipe bound, not latency bound;
+//   * the tile holds f32 (32 bytes per unit); the depthwise taps are f32 FMAs on the VALU in dw.hip's order (ky ascending,
+//     kx ascending; out-of-image taps skipped -- adding their zeros is the identity), so the depthwise output has the bits
+//     of front.hip's and dw.hip's;
+//   * outputs are stored directly (64 contiguous bytes per pixel and 16-channel block).
+// KS8 = Cin / 8 k-steps.
+template <int K, int KS8, int G, int CC, int NTHR>
+__global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params p) {
+    constexpr int NWAVE = NTHR / 64;
+    constexpr int PAD = K / 2;
+    constexpr int ROWS = HW7;
+    constexpr int NT = CC / 32, NCB = CC / 16;
+    constexpr int nrow = G * ROWS;
+    constexpr int nstrip = (nrow + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;                                                   // units of 32 bytes: 8 pixel slots f32
+    const float4v* Wl = reinterpret_cast<const float4v*>(smem + p.off_w);      // [KS8][NT][64 lanes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, lm = lane & 31;
+    const int Cin = p.Cin;
+    const int c0 = blockIdx.x * CC;
+    const int crop0 = blockIdx.y * G;
+    const int nlast = p.n - 1;
+
+    // ---- prologue: expand weights -> LDS; this wave's strip of pixel rows -> registers (all 24 k-steps: one round trip) --
+    constexpr int nwv = KS8 * NT * 64;
+    constexpr int WV = (nwv + NTHR - 1) / NTHR;
+    float4v wstage[WV];
+    {
+        const float4v* src = reinterpret_cast<const float4v*>(p.wep);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * NTHR;
+            if (v < nwv) {
+                const int ks = v / (NT * 64), r = v % (NT * 64);
+                wstage[i] = src[(size_t(ks) * p.NTe + (c0 >> 5)) * 64 + r];
+            }
+        }
+    }
+    auto a_offset = [&](int strip) -> unsigned {
+        int R = strip * 4 + (lm >> 3);
+        R = R < nrow ? R : nrow - 1;
+        const int cr = (R * 37) >> 8;                          // R / 7 for R < 64
+        const int row = R - cr * 7;
+        int gc = crop0 + cr;
+        gc = gc < nlast ? gc : nlast;
+        int px = lm & 7;
+        px = px < 7 ? px : 6;
+        return unsigned((gc * 49 + row * 7 + px) * Cin + g * 4) * 4u;
+    };
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
+    float4v a[KS8];
+    constexpr bool SPLIT = nstrip * NT <= NWAVE;               // (as the f16 kernel: one (strip, tile) task per wave)
+    int strip = SPLIT ? (wave < nstrip * NT ? wave % nstrip : nstrip) : wave;
+    const int t_lo = SPLIT ? wave / nstrip : 0, t_hi = SPLIT ? t_lo + 1 : NT;
+    if (strip < nstrip) {
+        const unsigned off = a_offset(strip);
+#pragma unroll
+        for (int ks = 0; ks < KS8; ++ks) a[ks] = *reinterpret_cast<const float4v*>(xb + off + ks * 32);
+    }
+    float bias_t[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias_t[t] = p.be[c0 + t * 32 + lm];
+    {
+        float4v* dst = reinterpret_cast<float4v*>(smem + p.off_w);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * NTHR;
+            if (v < nwv) dst[v] = wstage[i];
+        }
+    }
+    lds_barrier();
+
+    // ---- expand ----------------------------------------------------------------------------------------------------------
+    for (; strip < nstrip; strip += NWAVE) {
+        const bool more = strip + NWAVE < nstrip;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < t_lo || t >= t_hi) continue;               // (uniform)
+            float16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS8; ++ks) {
+                const float4v w = Wl[(ks * NT + t) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][u], w[u], acc, 0, 0, 0);
+            }
+            const float bias = bias_t[t];
+            const int ch = t * 32 + lm, cb = ch >> 4, cl = ch & 15;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int R = strip * 4 + qq;
+                if (R < nrow) {
+                    const int cr = (R * 37) >> 8, row = R - cr * 7;
+                    const int jq = cr >> 2, j = cr & 3;
+                    float4v o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = conv_swish<float>(acc[4 * qq + r] + bias);
+                    if (g) o[3] = 0.f;                          // pixel slot 7 is 'SAME' padding of the EXPANDED tensor
+                    unsigned char* ep = E + ((((jq * NCB + cb) * ROWS + row) * 64 + j * 16 + (cl ^ (j << 2))) << 5) + g * 16;
+                    *reinterpret_cast<float4v*>(ep) = o;
+                }
+            }
+        }
+        if (more) {
+            const unsigned off = a_offset(strip + NWAVE);
+#pragma unroll
+            for (int ks = 0; ks < KS8; ++ks) a[ks] = *reinterpret_cast<const float4v*>(xb + off + ks * 32);
+        }
+    }
+
+    // ---- depthwise taps on the VALU: items (crop quad, 16-channel block, x-group); lane = channel cl x crop j ------------
+    constexpr int NJQ = (G + 3) / 4;
+    constexpr int nitem = NJQ * NCB * 2;
+    const int cl = lane >> 2, j = lane & 3;
+    float wt[K * K];
+    float bdv = 0.f;
+    auto load_taps = [&](int it) {
+        const int cb = (it >> 1) % NCB;
+        const float* src = reinterpret_cast<const float*>(p.wdt) + c0 + cb * 16 + cl;
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) wt[q] = src[size_t(q) * p.Cexp];
+        bdv = p.bd[c0 + cb * 16 + cl];
+    };
+    int it = wave;
+    if (it < nitem) load_taps(it);
+    constexpr int W1Q = CC / 16;
+    float4v w1v[W1Q];
+    {
+        const int jo = (tid >> 2) & 63, q = tid & 3;
+        const float* wrow = p.w1t + size_t(jo < p.R ? jo : p.R - 1) * p.Cexp + c0 + q * (CC / 4);
+#pragma unroll
+        for (int i = 0; i < W1Q; ++i) w1v[i] = *reinterpret_cast<const float4v*>(wrow + 4 * i);
+    }
+    lds_barrier();
+
+    float* s_red = reinterpret_cast<float*>(smem + p.off_red);          // [G][2][CC]
+    float* s_sum = reinterpret_cast<float*>(smem + p.off_sum);          // [G][CC]
+    const int unit = j * 16 + (cl ^ (j << 2));
+    float* outp = reinterpret_cast<float*>(p.out);
+
+    for (; it < nitem; it += NWAVE) {
+        const int xgl = it & 1, cbq = it >> 1, cb = cbq % NCB, jq = cbq / NCB;       // (uniform)
+        const unsigned char* bp = E + ((((jq * NCB + cb) * ROWS) * 64 + unit) << 5);
+        float acc[ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r][i] = 0.f;
+        // the two x-groups read different pixels of the row: two unrolled bodies, chosen by the (uniform) group
+        auto rows = [&](auto xg) {
+            constexpr int XG = decltype(xg)::value;
+#pragma unroll
+            for (int er = 0; er < ROWS; ++er) {
+                const float4v lo = *reinterpret_cast<const float4v*>(bp + er * 2048);
+                const float4v hi = *reinterpret_cast<const float4v*>(bp + er * 2048 + 16);
+                const float in[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int d = er - ky + PAD;
+                    if (d >= 0 && d < ROWS) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int kx = 0; kx < K; ++kx) {
+                                const int px = 4 * XG + i + kx - PAD;          // input pixel of this tap (0..6 in the image)
+                                if (px >= 0 && px < HW7) acc[d][i] = fmaf(in[px], wt[ky * K + kx], acc[d][i]);
+                            }
+                    }
+                }
+            }
+        };
+        if (xgl == 0) rows(std::integral_constant<int, 0>{});
+        else rows(std::integral_constant<int, 1>{});
+        const float bd_this = bdv;
+        if (it + NWAVE < nitem) load_taps(it + NWAVE);
+        const int cr = jq * 4 + j;
+        const bool okc = cr < G && crop0 + cr < p.n;
+        float sum = 0.f;
+        float* ob = outp + (size_t(crop0 + cr) * 49 + 4 * xgl) * p.Cexp + c0 + cb * 16 + cl;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y = conv_swish<float>(acc[r][i] + bd_this);
+                if (okc && 4 * xgl + i < HW7) {
+                    sum += y;
+                    ob[size_t(r * 7 + i) * p.Cexp] = y;
+                }
+            }
+        if (cr < G) s_red[(cr * 2 + xgl) * CC + cb * 16 + cl] = okc ? sum : 0.f;
+    }
+    lds_barrier();
+
+    // ---- squeeze-excite, first half (as the f16 kernel) -------------------------------------------------------------------
+#pragma unroll
+    for (int i0 = 0; i0 < G * CC; i0 += NTHR) {
+        const int i = i0 + tid;
+        if (i < G * CC) {
+            const int cr = i / CC, c = i % CC;
+            s_sum[i] = s_red[(cr * 2) * CC + c] + s_red[(cr * 2 + 1) * CC + c];
+        }
+    }
+    lds_barrier();
+    {
+        const int jo = (tid >> 2) & 63, q = tid & 3;
+        for (int cr = tid >> 8; cr < G; cr += NTHR / 256) {
+            float accr = 0.0f;
+            if (jo < p.R) {
+                const float* sp = s_sum + cr * CC + q * (CC / 4);
+#pragma unroll
+                for (int i = 0; i < W1Q; ++i) {
+                    const float4v sv = *reinterpret_cast<const float4v*>(sp + 4 * i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accr = fmaf(sv[e], w1v[i][e], accr);
+                }
+            }
+            const float pair = accr + quad_xor1(accr);
+            const float tot = pair + quad_xor2(pair);
+            if (q == 0 && jo < p.RPse && crop0 + cr < p.n)
+                p.rpart[(size_t(crop0 + cr) * gridDim.x + blockIdx.x) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
+        }
+    }
+}
+
 struct OncePerDevice7 {
     std::atomic<bool> done[64];
     OncePerDevice7() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
 };
 
-template <int K, int KS, int G, int CC, int NTHR>
+template <int K, int KS, int G, int CC, int NTHR, bool F32>
 void launch_f7(const Front7Args& a, hipStream_t stream) {
     const Front7Plan& pl = a.plan;
     F7Params p{};
-    p.x = static_cast<const half_t*>(a.x);
-    p.wep = static_cast<const half_t*>(a.wep);
+    p.x = a.x;
+    p.wep = a.wep;
     p.be = a.be;
-    p.wdt = static_cast<const half_t*>(a.wdt);
+    p.wdt = a.wdt;
     p.bd = a.bd;
-    p.out = static_cast<half_t*>(a.out);
+    p.out = a.out;
     p.rpart = a.rpart;
     p.w1t = a.w1t;
     p.n = a.n;  p.Cin = a.Cin;  p.Cexp = a.Cexp;  p.NTe = a.NTe;
@@ -332,13 +574,15 @@ void launch_f7(const Front7Args& a, hipStream_t stream) {
     static OncePerDevice7 attr;
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
+    auto kern = [] {
+        if constexpr (F32) return &whenet_front7_f32_kernel<K, KS, G, CC, NTHR>;
+        else return &whenet_front7_kernel<K, KS, G, CC, NTHR>;
+    }();
     if (dev >= 0 && dev < 64 && !attr.done[dev].load(std::memory_order_acquire)) {
-        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front7_kernel<K, KS, G, CC, NTHR>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((whenet_front7_kernel<K, KS, G, CC, NTHR>), dim3(pl.chunks, ceil_div(a.n, pl.G)), dim3(NTHR), pl.lds_bytes,
-                       stream, p);
+    hipLaunchKernelGGL(kern, dim3(pl.chunks, ceil_div(a.n, pl.G)), dim3(NTHR), pl.lds_bytes, stream, p);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
@@ -346,7 +590,7 @@ void launch_f7(const Front7Args& a, hipStream_t stream) {
 
 // LDS: E [quads][CC / 16][7][64 units][16 B] | expand weights [KS][CC / 32][64][16 B] | output stage 2 KB per wave |
 // per-(crop, x-group) channel sums | per-crop channel sums
-Front7Plan make_front7_plan(int Cin, int Cexp, int G, int CC, int threads) {
+Front7Plan make_front7_plan(int dtype, int Cin, int Cexp, int G, int CC, int threads) {
     WHENET_REQUIRE((threads == 256 || threads == 512) && G >= 1 && G <= 8 && (CC == 32 || CC == 64 || CC == 128) && Cexp % CC == 0 &&
                        Cin % 16 == 0,
                    WHENET_EINVAL, "front7: bad tile plan");
@@ -355,11 +599,12 @@ Front7Plan make_front7_plan(int Cin, int Cexp, int G, int CC, int threads) {
     p.G = G;
     p.CC = CC;
     p.chunks = Cexp / CC;
-    const int njq = (G + 3) / 4, ncb = CC / 16, ks = Cin / 16, nt = CC / 32;
-    const size_t e_bytes = size_t(njq) * ncb * HW7 * 1024;
+    const bool f32 = dtype == WHENET_F32;
+    const int njq = (G + 3) / 4, ncb = CC / 16, ks = Cin / (f32 ? 8 : 16), nt = CC / 32;
+    const size_t e_bytes = size_t(njq) * ncb * HW7 * 64 * (f32 ? 32 : 16);
     p.off_w = int(e_bytes);
     p.off_stage = p.off_w + ks * nt * 1024;
-    p.off_red = p.off_stage + (threads / 64) * 2048;
+    p.off_red = p.off_stage + (f32 ? 0 : (threads / 64) * 2048);     // (the f32 kernel stores its outputs directly)
     p.off_sum = p.off_red + G * 2 * CC * 4;
     p.lds_bytes = size_t(p.off_sum) + size_t(G) * CC * 4;
     return p;
@@ -370,7 +615,12 @@ Front7Plan make_front7_plan(int Cin, int Cexp, int G, int CC, int threads) {
 // crops per launch up, groups of 2 below (twice the workgroups when the launch cannot fill the chip anyway: 6.6 vs 7.8 us at
 // one crop, 7.5 vs 8.3 us at 16).  The channel chunk must NOT depend on n: the squeeze-excite partial vectors are summed
 // per chunk, so only plans with the same CC give a crop the same bits; the group size changes nothing in them.
-Front7Plan front7_plan_for(int Cin, int Cexp, int n) { return make_front7_plan(Cin, Cexp, n <= 16 ? 2 : 4, 64, 512); }
+// f32: the expand phase is matrix-pipe bound (v_mfma_f32_32x32x2_f32: 64 cycles each, 96 per task), so a single crop travels
+// alone (G = 1: 4 tasks on the 4 SIMDs instead of 8 half-empty ones).
+Front7Plan front7_plan_for(int dtype, int Cin, int Cexp, int n) {
+    const int G = (dtype == WHENET_F32 && n == 1) ? 1 : (n <= 16 ? 2 : 4);
+    return make_front7_plan(dtype, Cin, Cexp, G, 64, 512);
+}
 
 bool front7_supported(int k, int s, int H, int Cin) { return (k == 3 || k == 5) && s == 1 && H == HW7 && Cin == 192; }
 
@@ -378,8 +628,19 @@ void launch_front7(const Front7Args& a, hipStream_t stream) {
     WHENET_REQUIRE(front7_supported(a.k, 1, HW7, a.Cin) && a.w1t != nullptr && a.R >= 1 && a.R <= 64 && a.n >= 1, WHENET_EINVAL,
                    "front7: 7 x 7 maps, 3x3 / 5x5 stride-1 kernels, Cin = 192, squeeze-excite reduce conv in the kernel");
     const int key = ((a.k * 10 + a.plan.G) * 1000 + a.plan.CC) * 1000 + a.plan.threads;
+    if (a.dtype == WHENET_F32) {
+        switch (key) {
+#define F7_CASE32(K, G, CC, T) case ((K * 10 + G) * 1000 + CC) * 1000 + T: launch_f7<K, 24, G, CC, T, true>(a, stream); break;
+            F7_CASE32(5, 4, 64, 512) F7_CASE32(3, 4, 64, 512)
+            F7_CASE32(5, 2, 64, 512) F7_CASE32(3, 2, 64, 512)
+            F7_CASE32(5, 1, 64, 512) F7_CASE32(3, 1, 64, 512)
+#undef F7_CASE32
+            default: throw Error(WHENET_EINVAL, "front7: no f32 instantiation for this (kernel, G, CC, lanes) plan");
+        }
+        return;
+    }
     switch (key) {
-#define F7_CASE(K, G, CC, T) case ((K * 10 + G) * 1000 + CC) * 1000 + T: launch_f7<K, 12, G, CC, T>(a, stream); break;
+#define F7_CASE(K, G, CC, T) case ((K * 10 + G) * 1000 + CC) * 1000 + T: launch_f7<K, 12, G, CC, T, false>(a, stream); break;
         F7_CASE(5, 4, 64, 512) F7_CASE(3, 4, 64, 512)
         F7_CASE(5, 2, 64, 512) F7_CASE(3, 2, 64, 512)
 #ifdef WHENET_FRONT7_ALL_PLANS                   // the probe's sweep (tools/probes/front7_probe.hip)
@@ -398,8 +659,9 @@ void launch_front7(const Front7Args& a, hipStream_t stream) {
     }
 }
 
-std::string kernel_name_front7(int k, const Front7Plan& p) {
-    return "whenet_front7_kernel<" + std::to_string(k) + ", 12, " + std::to_string(p.G) + ", " + std::to_string(p.CC) + ", " +
+std::string kernel_name_front7(int dtype, int k, const Front7Plan& p) {
+    return std::string(dtype == WHENET_F32 ? "whenet_front7_f32_kernel<" : "whenet_front7_kernel<") + std::to_string(k) +
+           (dtype == WHENET_F32 ? ", 24, " : ", 12, ") + std::to_string(p.G) + ", " + std::to_string(p.CC) + ", " +
            std::to_string(p.threads) + ">";
 }
 

@@ -203,7 +203,7 @@ void launch_front2(const Front2Args& a, hipStream_t stream);
 std::string kernel_name_front2(int k, int s, int kse, int threads, int xs, bool gated);
 
 // ---- front7.hip -------------------------------------------------------------------------
-// f16, the 7 x 7 blocks (13-16): the same stage with a GROUP of G crops per workgroup, the image-only LDS tile (no halo)
+// the 7 x 7 blocks (13-16), both dtypes: the same stage with a GROUP of G crops per workgroup, the image-only LDS tile (no halo)
 // and the chunk's expand weights staged once in LDS (round 4).
 struct Front7Plan {
     int threads = 512;     // lanes per workgroup (256 | 512)
@@ -213,16 +213,17 @@ struct Front7Plan {
     int off_w = 0, off_stage = 0, off_red = 0, off_sum = 0;
     size_t lds_bytes = 0;
 };
-Front7Plan make_front7_plan(int Cin, int Cexp, int G, int CC, int threads);
-Front7Plan front7_plan_for(int Cin, int Cexp, int n);
+Front7Plan make_front7_plan(int dtype, int Cin, int Cexp, int G, int CC, int threads);
+Front7Plan front7_plan_for(int dtype, int Cin, int Cexp, int n);
 bool front7_supported(int k, int s, int H, int Cin);
 struct Front7Args {
-    const void* x;         // [n,7,7,Cin] half  block input
+    int dtype = WHENET_F16;
+    const void* x;         // [n,7,7,Cin] T  block input
     const void* wep;       // packed expand weights (MFMA fragment order, snapshot.h)
     const float* be;       // [Cexp]
-    const void* wdt;       // pack_dw_toeplitz(w, k, 1, Cexp, 4 - k / 2) image of the depthwise kernel
+    const void* wdt;       // f16: pack_dw_toeplitz(w, k, 1, Cexp, 4 - k / 2) image of the depthwise kernel; f32: the kernel, [k*k][Cexp]
     const float* bd;       // [Cexp]
-    void* out;             // [n,7,7,Cexp] half
+    void* out;             // [n,7,7,Cexp] T
     float* rpart;          // [n][chunks][RP] this workgroup's share of the SE reduce conv, per crop (unscaled)
     const float* w1t;      // [R][Cexp] se_reduce kernel, transposed
     int R;
@@ -230,7 +231,7 @@ struct Front7Args {
     Front7Plan plan;
 };
 void launch_front7(const Front7Args& a, hipStream_t stream);
-std::string kernel_name_front7(int k, const Front7Plan& p);
+std::string kernel_name_front7(int dtype, int k, const Front7Plan& p);
 
 // ---- yolo.hip ---------------------------------------------------------------------------
 // YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.

@@ -15,6 +15,8 @@
 #include "device_math.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace whenet {
 
 namespace {
@@ -259,7 +261,125 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
     }
 }
 
+// ---- f32 configuration on the matrix cores (round 4) -----------------------------------------------------------------------
+// The same decomposition with v_mfma_f32_32x32x2_f32 -- exact f32, an fmaf chain in k order, so the result has the bits of
+// the scalar kernel above (k = (ky, kx, ci) ascending): the 9 contiguous (kx, ci) values of a row are 5 k-pairs (the tenth
+// value is a zero weight), 15 MFMAs per 32-pixel strip instead of 864 FMAs per pixel in the VALU.  Rows and LUT stay f32.
+constexpr int OPITCH32 = 36;                         // floats per staged output pixel (144 B: 16-byte aligned)
+
+template <bool INF32>
+__global__ __launch_bounds__(256) void whenet_stem_mfma_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ lut) {
+    __shared__ float s_lut[3 * 256];
+    __shared__ __attribute__((aligned(16))) float s_img[MIN_ROWS * ROW_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_out[4][32 * OPITCH32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, lm = lane & 31;
+    const int oy0 = blockIdx.x * MR;
+    const int b = blockIdx.y;
+
+    // weight operands: MFMA u of row ky contracts k = 2 u + g of the row's 9 values (k = 9: zero)
+    float wv[3][5];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int j = 2 * u + g;
+            wv[ky][u] = (j < 9) ? w[(ky * 9 + j) * STEM_C + lm] : 0.0f;
+        }
+    float4v bv[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) bv[qq] = *reinterpret_cast<const float4v*>(bias + 8 * qq + 4 * g);
+
+    constexpr int NLD = (MIN_ROWS * ROW_DWORDS + 255) / 256;
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in + size_t(b) * IMG * IMG * 3);
+    const float4v* inf = reinterpret_cast<const float4v*>(reinterpret_cast<const float*>(in) + size_t(b) * IMG * IMG * 3);
+    uint32_t raw[INF32 ? 1 : NLD];
+    float4v rawf[INF32 ? NLD : 1];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int d = tid + 256 * i;
+        const int r = d / ROW_DWORDS, j = d - r * ROW_DWORDS;
+        const int iy = 2 * oy0 + r;
+        const bool ok = d < MIN_ROWS * ROW_DWORDS && iy < IMG;
+        if constexpr (INF32) rawf[i] = ok ? inf[iy * ROW_DWORDS + j] : float4v{0.f, 0.f, 0.f, 0.f};
+        else raw[i] = ok ? in32[iy * ROW_DWORDS + j] : 0u;
+    }
+    if constexpr (!INF32)
+        for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = lut[i];
+    if (tid < MIN_ROWS * 4) s_img[(tid >> 2) * ROW_FLOATS + 672 + (tid & 3)] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int d = tid + 256 * i;
+        if (d >= MIN_ROWS * ROW_DWORDS) continue;
+        const int r = d / ROW_DWORDS, j = d - r * ROW_DWORDS;
+        const int iy = 2 * oy0 + r;
+        float* dst = &s_img[r * ROW_FLOATS + 4 * j];
+        if (INF32) {
+            dst[0] = rawf[i][0]; dst[1] = rawf[i][1]; dst[2] = rawf[i][2]; dst[3] = rawf[i][3];     // (zero beyond the image)
+        } else if (iy < IMG) {
+            const uint32_t v = raw[i];
+            int ch = (4 * j) % 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                dst[q] = s_lut[ch * 256 + ((v >> (8 * q)) & 0xff)];
+                ch = (ch == 2) ? 0 : ch + 1;
+            }
+        } else {          // bottom pad row (iy == 224): zero in the normalised domain
+            dst[0] = dst[1] = dst[2] = dst[3] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    constexpr int NSTRIP = MR * STEM_HW / 32;        // 14
+    float* so = s_out[wave];
+    float* obase = out + (size_t(b) * STEM_HW + oy0) * STEM_HW * STEM_C;
+    for (int strip = wave; strip < NSTRIP; strip += 4) {
+        const int p = strip * 32 + lm;
+        const int oyl = p / STEM_HW, ox = p - oyl * STEM_HW;
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = &s_img[(2 * oyl + ky) * ROW_FLOATS + ox * 6 + g];
+#pragma unroll
+            for (int u = 0; u < 5; ++u)                        // (u = 4, g = 1 reads the next pixel's value against a zero weight)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ky][u], row[2 * u], acc, 0, 0, 0);
+        }
+        // BN bias + Swish; lane holds channels 8*qq + 4*g + r of pixel lm
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            float4v o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = conv_swish<float>(acc[4 * qq + r] + bv[qq][r]);
+            *reinterpret_cast<float4v*>(so + lm * OPITCH32 + 8 * qq + 4 * g) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's own LDS region: no barrier needed)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            const int px = idx >> 3, part = idx & 7;
+            const float4v v = *reinterpret_cast<const float4v*>(so + px * OPITCH32 + part * 4);
+            *reinterpret_cast<float4v*>(obase + size_t(strip * 32 + px) * STEM_C + part * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next strip overwrites
+    }
+}
+
 }  // namespace
+
+// WHENET_STEM_SCALAR_F32=1 (read once): the f32 stem as round 3's scalar kernel -- the two forms are compared bitwise by
+// tests/test_gpu_parity.py::test_f32_stem_on_the_matrix_cores_has_the_scalar_kernels_bits
+static bool stem_scalar_f32() {
+    static const bool v = [] { const char* e = getenv("WHENET_STEM_SCALAR_F32"); return e && e[0] == '1'; }();
+    return v;
+}
 
 void launch_stem(const StemArgs& a, int dtype, hipStream_t stream) {
     dim3 grid(STEM_HW / ROWS_PER_BLOCK, a.n);
@@ -269,20 +389,27 @@ void launch_stem(const StemArgs& a, int dtype, hipStream_t stream) {
         if (dtype == WHENET_F16)
             hipLaunchKernelGGL((whenet_stem_mfma_kernel<true>), grid_m, dim3(256), 0, stream, src,
                                static_cast<half_t*>(a.out), a.w, a.bias, a.lut);
-        else
+        else if (stem_scalar_f32())
             hipLaunchKernelGGL((whenet_stem_kernel<float, true>), grid, dim3(256), 0, stream, src,
+                               static_cast<float*>(a.out), a.w, a.bias, a.lut);
+        else
+            hipLaunchKernelGGL((whenet_stem_mfma_f32_kernel<true>), grid_m, dim3(256), 0, stream, src,
                                static_cast<float*>(a.out), a.w, a.bias, a.lut);
     } else if (dtype == WHENET_F16)
         hipLaunchKernelGGL((whenet_stem_mfma_kernel<false>), grid_m, dim3(256), 0, stream, a.in,
                            static_cast<half_t*>(a.out), a.w, a.bias, a.lut);
-    else
+    else if (stem_scalar_f32())
         hipLaunchKernelGGL((whenet_stem_kernel<float, false>), grid, dim3(256), 0, stream, a.in,
+                           static_cast<float*>(a.out), a.w, a.bias, a.lut);
+    else
+        hipLaunchKernelGGL((whenet_stem_mfma_f32_kernel<false>), grid_m, dim3(256), 0, stream, a.in,
                            static_cast<float*>(a.out), a.w, a.bias, a.lut);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
 const char* kernel_name_stem(int dtype) {
-    return dtype == WHENET_F16 ? "whenet_stem_mfma_kernel<false>" : "whenet_stem_kernel<float, false>";
+    return dtype == WHENET_F16 ? "whenet_stem_mfma_kernel<false>"
+                               : (stem_scalar_f32() ? "whenet_stem_kernel<float, false>" : "whenet_stem_mfma_f32_kernel<false>");
 }
 
 }  // namespace whenet

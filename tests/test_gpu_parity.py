@@ -105,6 +105,27 @@ def test_stem_kernel(handle, taps):
     assert rel_err(got, taps["stem"]) < tol(handle)
 
 
+def test_f32_stem_on_the_matrix_cores_has_the_scalar_kernels_bits(tmp_path, golden):
+    """Round 4: the f32 stem runs on v_mfma_f32_32x32x2_f32 (exact f32: an fmaf chain in k order).  Its output must be
+    BITWISE the scalar kernel's (WHENET_STEM_SCALAR_F32=1, read once per process: two child processes)."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = ("import sys, numpy as np; sys.path.insert(0, sys.argv[1] + '/headposeestimation-whenet_amd'); sys.path.insert(0, sys.argv[1]);"
+            "import torch; from whenet_hip import _lib, weights as W;"
+            "h = _lib.Handle(W.pack(W.synthetic(1234)), device=0, dtype=_lib.F32);"
+            "c = np.load(sys.argv[1] + '/tests/golden/golden_crops.npy')[:3];"
+            "np.savez(sys.argv[2], stem=h.op_stem(c), logits=h.forward(c)[2]); h.close()")
+    outs = []
+    for flag in ("0", "1"):
+        f = str(tmp_path / f"stem{flag}.npz")
+        env = dict(os.environ, WHENET_STEM_SCALAR_F32=flag)
+        r = subprocess.run([sys.executable, "-c", code, root, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(dict(np.load(f)))
+    assert np.array_equal(outs[0]["stem"], outs[1]["stem"]) and np.array_equal(outs[0]["logits"], outs[1]["logits"])
+
+
 @pytest.mark.parametrize("index", list(range(1, 17)))
 def test_mbconv_block_kernels(handle, taps, index):
     """expand GEMM, depthwise, SE gate, project GEMM (+skip) of every block, each on the
@@ -157,13 +178,17 @@ def test_mbconv_block_kernels(handle, taps, index):
         assert rel_err(r["out"], taps[f"{p}/out"]) < 3 * t, "out"
 
 
-def test_front7_group_kernel(blob, taps, golden):
-    """Round 4: blocks 13-16 (7 x 7 maps) of an f16 handle run front7.hip -- a group of crops per workgroup (2 crops up to 16
-    crops per launch, 4 above), the chunk's expand weights staged once in LDS.  Each block on the oracle's own input:
-    within the kernel tolerance of the oracle and of round 3's kernel (option front7=0); and the group size changes no
-    bit: crops travel through launches of 1, 2, 3, 16, 17 and 21 crops (tail groups of both sizes) with identical results."""
-    t = 1.5e-2
-    with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+@pytest.mark.parametrize("dt", DTYPES, ids=[d[0] for d in DTYPES])
+def test_front7_group_kernel(blob, taps, golden, dt):
+    """Round 4: blocks 13-16 (7 x 7 maps) run front7.hip -- a group of crops per workgroup (2 crops up to 16 crops per
+    launch, 4 above), the chunk's expand weights staged once in LDS, the image-only tile.  Each block on the oracle's own
+    input: within the kernel tolerance of the oracle and of round 3's kernel (option front7=0) -- for f32 the depthwise
+    output is BITWISE round 3's (same fmaf chains in the same order; only the grouping of the squeeze-excite sums
+    differs); and the group size changes no bit: crops travel through launches of 1, 2, 3, 16, 17 and 21 crops (tail
+    groups of both sizes) with identical results."""
+    name, dtype = dt
+    t = 1.5e-2 if name == "f16" else 2e-5
+    with _lib.Handle(blob, device=0, dtype=dtype) as h:
         for index in (13, 14, 15, 16):
             x = taps[f"b{index - 1}/out"].astype(np.float32)
             h.set_option("se_fuse", 0)
@@ -172,10 +197,14 @@ def test_front7_group_kernel(blob, taps, golden):
             r3 = h.op_block(index, x)
             h.set_option("front7", 1)
             h.set_option("se_fuse", 1)
-            assert not np.array_equal(r7["dw"], r3["dw"]), "front7 is not active"
+            if name == "f32":
+                assert np.array_equal(r7["dw"], r3["dw"]), "f32 front7: depthwise output differs from front.hip's"
+                assert not np.array_equal(r7["gate"], r3["gate"]), "front7 is not active"
+            else:
+                assert not np.array_equal(r7["dw"], r3["dw"]), "front7 is not active"
             assert rel_err(r7["dw"], r3["dw"]) < t and rel_err(r7["gate"], r3["gate"]) < 2 * t and rel_err(r7["out"], r3["out"]) < 3 * t
             assert rel_err(r7["dw"], taps[f"b{index}/dw"]) < 2 * t and rel_err(r7["out"], taps[f"b{index}/out"]) < 3 * t
-            # the same block on a ragged batch: 21 copies + permutation -> every crop bitwise what it is alone
+            # the same block on a ragged batch of 21: every crop bitwise what it is alone
             xs = np.concatenate([x] * 11)[:21]
             big = h.op_block(index, xs)
             for i in range(21):
@@ -187,7 +216,7 @@ def test_front7_group_kernel(blob, taps, golden):
             assert np.array_equal(l, l21[lo:hi]) and np.array_equal(y, y21[lo:hi]), (lo, hi)
         h.set_option("front7", 0)
         y0, a0, l0 = h.forward(crops)
-        assert not np.array_equal(l0, l21) and np.abs(l0 - l21).max() < 0.5
+        assert not np.array_equal(l0, l21) and np.abs(l0 - l21).max() < (0.5 if name == "f16" else 2e-3)
 
 
 def r7_like(h, index, x1):

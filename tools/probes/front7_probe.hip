@@ -173,7 +173,7 @@ int main() {
         printf("%s k%d 7x7 Cin%d Cexp%d\n", sh.name, K, Cin, Cexp);
         for (const Cfg& c : cfgs) {
             Front7Plan pl;
-            try { pl = make_front7_plan(Cin, Cexp, c.G, c.CC, c.thr); } catch (const Error& e) { printf("  plan G=%d CC=%d: %s\n", c.G, c.CC, e.what()); continue; }
+            try { pl = make_front7_plan(WHENET_F16, Cin, Cexp, c.G, c.CC, c.thr); } catch (const Error& e) { printf("  plan G=%d CC=%d: %s\n", c.G, c.CC, e.what()); continue; }
             if (pl.lds_bytes > 160 * 1024) { printf("  plan G=%d CC=%d thr=%d: lds %zu too large\n", c.G, c.CC, c.thr, pl.lds_bytes); continue; }
             char what[64];
             snprintf(what, sizeof what, "G=%d CC=%d thr=%d lds=%zu", c.G, c.CC, c.thr, pl.lds_bytes);
@@ -205,7 +205,7 @@ int main() {
             }
             total_bad += bad;
             {   // the group size changes nothing in a crop's bits: G = 4 / CC = 64 is the reference plan
-                const Front7Plan ref = make_front7_plan(Cin, Cexp, 4, 64, 512);
+                const Front7Plan ref = make_front7_plan(WHENET_F16, Cin, Cexp, 4, 64, 512);
                 run7(ref, 9, d_x);
                 CK(hipStreamSynchronize(st));
                 std::vector<half_t> o0(size_t(9) * 49 * Cexp), o1(o0.size());
@@ -250,7 +250,7 @@ int main() {
         printf("  front2.hip (round 3)          : n=256 %7.2f us  n=64 %7.2f us  n=16 %6.2f us\n", time_fn(f2, 256), time_fn(f2, 64), time_fn(f2, 16));
 #ifdef WHENET_STAMPS
         for (const Cfg& c : {Cfg{4, 64, 512}, Cfg{4, 64, 256}}) {
-            const Front7Plan pl = make_front7_plan(Cin, Cexp, c.G, c.CC, c.thr);
+            const Front7Plan pl = make_front7_plan(WHENET_F16, Cin, Cexp, c.G, c.CC, c.thr);
             for (int n : {256, 64}) {
                 const size_t nwg = size_t(pl.chunks) * ceil_div(n, pl.G);
                 long long* d_st; CK(hipMalloc(&d_st, nwg * 8 * sizeof(long long)));
