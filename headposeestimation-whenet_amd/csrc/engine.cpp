@@ -195,6 +195,10 @@ void Engine::set_option(const std::string& key, long value) {
         front_impl_ = int(value);
         sync();
         drop_graphs();
+    } else if (key == "head_fuse") {
+        head_fuse_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "front7") {
         front7_ = value != 0;
         sync();
@@ -607,6 +611,33 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
           [&] { launch_stem(a, dtype_, s); });
     }
     void* cur = enqueue_blocks(1, int(blocks_.size()), v, v.x0, n, s, rec);
+    const bool fuse_head = head_fuse_ && pw_impl_ == 0 && split_heads_ && head7_supported(dtype_, head_.K, head_.N, 49) &&
+                           partial_per_crop_ >= size_t(heads_split()) * N_LOGITS;
+    if (fuse_head) {
+        // head conv + GlobalAveragePooling2D as one kernel (head7.hip): v.hc receives the pooled features [n][1280] f32
+        Head7Args a{};
+        a.x = cur;
+        a.wep = head_.wp;
+        a.bias = head_.bias;
+        a.feat = reinterpret_cast<float*>(v.hc);
+        a.K = head_.K;
+        a.N = head_.N;
+        a.NTILES = head_.NTILES;
+        a.n = n;
+        R("head", "pw", kernel_name_head7(n).c_str(), double(n) * (49.0 * a.K * es + a.N * 4.0), 2.0 * n * 49.0 * a.K * a.N,
+          [&] { launch_head7(a, s); });
+        HeadsArgs hargs{};
+        hargs.feat_in = reinterpret_cast<const float*>(v.hc);
+        hargs.w = d_dense_w_;
+        hargs.b = d_dense_b_;
+        hargs.logits = d_logits;
+        hargs.ypr = d_ypr;
+        hargs.argmax = d_amax;
+        hargs.n = n;
+        R("heads", "heads", "whenet_heads_split_kernel<float, true>", double(n) * ((FEAT + N_LOGITS + 6) * 4.0) + double(FEAT) * N_LOGITS * 4.0,
+          2.0 * n * FEAT * N_LOGITS, [&] { launch_heads_split(hargs, v.partial, v.hcount, dtype_, s); });
+        return;
+    }
     {
         PwArgs a{};
         a.a = cur;
@@ -636,7 +667,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         // (v.partial is free here: the last squeeze-excite is long done)
         const bool split = split_heads_ && partial_per_crop_ >= size_t(heads_split()) * N_LOGITS;
         const std::string hname = std::string(split ? "whenet_heads_split_kernel<" : "whenet_heads_kernel<") +
-                                  (dtype_ == WHENET_F16 ? "_Float16>" : "float>");
+                                  (dtype_ == WHENET_F16 ? "_Float16" : "float") + (split ? ", false>" : ">");
         R("heads", "heads", hname.c_str(),
           double(n) * (HC_ELEMS * es + (N_LOGITS + 6) * 4.0) + double(FEAT) * N_LOGITS * 4.0, 2.0 * n * FEAT * N_LOGITS,
           [&] {

@@ -90,25 +90,40 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
     float* d_feat = static_cast<float*>(tmp.get(N * FEAT * sizeof(float)));
     WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
     launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
-    PwArgs a{};
-    a.a = x0_;
-    a.wp = head_.wp;
-    a.wdense = head_.wdense;
-    a.bias = head_.bias;
-    a.out = hc_;
-    a.M = n * 49;
-    a.K = head_.K;
-    a.N = head_.N;
-    a.KS = head_.KS;
-    a.NTILES = head_.NTILES;
-    a.HW = 49;
-    a.act = ACT_SWISH;
-    launch_pw(a, dtype_, pw_impl_, num_cus_, stream_);
+    const bool fuse_head = head_fuse_ && pw_impl_ == 0 && head7_supported(dtype_, head_.K, head_.N, 49);
     HeadsArgs h{};
-    h.x = hc_;
+    if (fuse_head) {          // the forward's form: head conv + pooling as one kernel (head7.hip), Dense heads on its features
+        Head7Args a{};
+        a.x = x0_;
+        a.wep = head_.wp;
+        a.bias = head_.bias;
+        a.feat = d_feat;
+        a.K = head_.K;
+        a.N = head_.N;
+        a.NTILES = head_.NTILES;
+        a.n = n;
+        launch_head7(a, stream_);
+        h.feat_in = d_feat;
+    } else {
+        PwArgs a{};
+        a.a = x0_;
+        a.wp = head_.wp;
+        a.wdense = head_.wdense;
+        a.bias = head_.bias;
+        a.out = hc_;
+        a.M = n * 49;
+        a.K = head_.K;
+        a.N = head_.N;
+        a.KS = head_.KS;
+        a.NTILES = head_.NTILES;
+        a.HW = 49;
+        a.act = ACT_SWISH;
+        launch_pw(a, dtype_, pw_impl_, num_cus_, stream_);
+        h.x = hc_;
+        h.feat = d_feat;
+    }
     h.w = d_dense_w_;
     h.b = d_dense_b_;
-    h.feat = d_feat;
     h.logits = o_logits_;
     h.ypr = o_ypr_;
     h.argmax = o_amax_;

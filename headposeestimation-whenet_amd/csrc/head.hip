@@ -149,7 +149,8 @@ __device__ __forceinline__ void st_l2_f32(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T>
+// FEAT_IN: x is the pooled feature vector [n][1280] f32 (head7.hip pooled it), not the head conv's output tensor
+template <typename T, bool FEAT_IN>
 __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bvec,
                                                                 float* __restrict__ logits_out, float* __restrict__ ypr,
@@ -166,7 +167,9 @@ __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __rest
     const int wave = tid >> 6, lane = tid & 63;
 
     // ---- GAP over the 49 positions for this workgroup's channels: lane <-> (4 channels, positions p = grp mod 6)
-    {
+    if constexpr (FEAT_IN) {
+        if (tid < HCH) s_feat[tid] = reinterpret_cast<const float*>(x)[size_t(b) * FEAT + q * HCH + tid];
+    } else {
         using V4 = T __attribute__((ext_vector_type(4)));
         const T* xb = x + size_t(b) * HW * FEAT + q * HCH;
         const int c4 = tid % (HCH / 4), grp = tid / (HCH / 4);
@@ -186,10 +189,12 @@ __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __rest
         }
     }
     __syncthreads();
-    if (tid < HCH)
-        s_feat[tid] = (((s_gap[0][tid] + s_gap[1][tid]) + (s_gap[2][tid] + s_gap[3][tid])) + (s_gap[4][tid] + s_gap[5][tid])) *
-                      (1.0f / 49.0f);
-    __syncthreads();
+    if constexpr (!FEAT_IN) {
+        if (tid < HCH)
+            s_feat[tid] = (((s_gap[0][tid] + s_gap[1][tid]) + (s_gap[2][tid] + s_gap[3][tid])) + (s_gap[4][tid] + s_gap[5][tid])) *
+                          (1.0f / 49.0f);
+        __syncthreads();
+    }
 
     // ---- Dense partial: 8 waves x 40 channels, lane l owns logits 4l..4l+3 --------------------------------
     {
@@ -287,12 +292,16 @@ __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __rest
 int heads_split() { return HSPLIT; }
 
 void launch_heads_split(const HeadsArgs& a, float* part, unsigned* count, int dtype, hipStream_t stream) {
-    WHENET_REQUIRE(a.x != nullptr && part != nullptr && count != nullptr, WHENET_EINVAL, "heads (split): missing buffers");
-    if (dtype == WHENET_F16)
-        hipLaunchKernelGGL(whenet_heads_split_kernel<half_t>, dim3(HSPLIT, a.n), dim3(512), 0, stream,
+    WHENET_REQUIRE((a.x != nullptr || a.feat_in != nullptr) && part != nullptr && count != nullptr, WHENET_EINVAL,
+                   "heads (split): missing buffers");
+    if (a.feat_in != nullptr)
+        hipLaunchKernelGGL((whenet_heads_split_kernel<float, true>), dim3(HSPLIT, a.n), dim3(512), 0, stream, a.feat_in, a.w, a.b,
+                           a.logits, a.ypr, a.argmax, part, count);
+    else if (dtype == WHENET_F16)
+        hipLaunchKernelGGL((whenet_heads_split_kernel<half_t, false>), dim3(HSPLIT, a.n), dim3(512), 0, stream,
                            static_cast<const half_t*>(a.x), a.w, a.b, a.logits, a.ypr, a.argmax, part, count);
     else
-        hipLaunchKernelGGL(whenet_heads_split_kernel<float>, dim3(HSPLIT, a.n), dim3(512), 0, stream,
+        hipLaunchKernelGGL((whenet_heads_split_kernel<float, false>), dim3(HSPLIT, a.n), dim3(512), 0, stream,
                            static_cast<const float*>(a.x), a.w, a.b, a.logits, a.ypr, a.argmax, part, count);
     WHENET_HIP_CHECK(hipGetLastError());
 }

@@ -126,6 +126,20 @@ void launch_heads(const HeadsArgs& a, int dtype, hipStream_t stream);
 void launch_heads_split(const HeadsArgs& a, float* part, unsigned* count, int dtype, hipStream_t stream);
 int heads_split();
 
+// ---- head7.hip --------------------------------------------------------------------------
+// f16: head conv 1x1 (320 -> 1280) + BN + Swish fused with GlobalAveragePooling2D (whenet.py:8-10): only the pooled
+// features leave the kernel.  A group of crops per workgroup, every crop on its own two MFMA strips (batch-invariant).
+struct Head7Args {
+    const void* x;         // [n,7,7,K] half
+    const void* wep;       // packed head-conv weights (MFMA fragment order, snapshot.h)
+    const float* bias;     // [N]
+    float* feat;           // [n][N] pooled features, f32
+    int K, N, NTILES, n;
+};
+bool head7_supported(int dtype, int K, int N, int HW);
+void launch_head7(const Head7Args& a, hipStream_t stream);
+std::string kernel_name_head7(int n);
+
 // ---- front.hip --------------------------------------------------------------------------
 // expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).
 struct FrontPlan {

@@ -260,6 +260,38 @@ def test_head_kernels(handle, taps):
     assert np.abs(r["logits"] - taps["logits"]).max() < (2e-3 if handle.name == "f32" else 1.0)
 
 
+def test_head_conv_fused_with_pooling(blob, taps, golden):
+    """Round 4 ("K-pw fused with GAP"; whenet.py:8-10): the f16 head conv pools its own output (head7.hip) --
+    a group of crops per workgroup, every crop on its own two MFMA strips, pooled in f32 before any rounding.  Against the
+    oracle's pooled features, against round 3's two stages (option head_fuse=0), and bitwise the same for a crop
+    whatever launch it travels in (groups of 2 crops up to 16 per launch, of 4 above: 1, 2, 3, 16, 17, 21 crops)."""
+    x = taps["b16/out"].astype(np.float32)
+    want = taps["head"].mean(axis=(1, 2))
+    with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+        r1 = h.op_head(x)
+        h.set_option("head_fuse", 0)
+        r0 = h.op_head(x)
+        h.set_option("head_fuse", 1)
+        assert not np.array_equal(r1["feat"], r0["feat"]), "head_fuse is not active"
+        assert rel_err(r1["feat"], want) < 1.5e-2 and rel_err(r0["feat"], want) < 3 * 1.5e-2
+        # pooled in f32 before the rounding to f16: closer to the oracle than the two-stage form
+        assert np.abs(r1["feat"] - want).mean() <= np.abs(r0["feat"] - want).mean()
+        assert np.abs(r1["logits"] - taps["logits"]).max() < 1.0
+        xs = np.concatenate([x] * 11)[:21]
+        big = h.op_head(xs)
+        for i in (0, 1, 15, 16, 17, 20):
+            one = h.op_head(xs[i:i + 1])
+            assert np.array_equal(big["feat"][i], one["feat"][0]) and np.array_equal(big["logits"][i], one["logits"][0]), i
+        crops = np.concatenate([golden["crops"], synth.scene_crops(13, seed=78)])          # 21 crops
+        y21, a21, l21 = h.forward(crops)
+        for lo, hi in ((0, 1), (1, 3), (0, 16), (4, 21), (20, 21)):
+            y, a, l = h.forward(crops[lo:hi])
+            assert np.array_equal(l, l21[lo:hi]) and np.array_equal(y, y21[lo:hi]), (lo, hi)
+        h.set_option("head_fuse", 0)
+        y0, a0, l0 = h.forward(crops)
+        assert not np.array_equal(l0, l21) and np.abs(l0 - l21).max() < 0.5
+
+
 def test_decode_kernel(handle):
     """utils.py:7-11 + whenet.py:28-33 on the device vs numpy float64, incl. ties and extremes."""
     rng = np.random.default_rng(5)
