@@ -569,7 +569,9 @@ std::vector<half_t> pack_dw_toeplitz(const std::vector<float>& w, int k, int s, 
 Front2Plan make_front2_plan(int k, int s, int Ho, int Cexp, int CC, int TH, int TXG, int threads, int xs) {
     const int OXG = ceil_div(Ho, 4), nch = (3 * s + k + xs + 3) / 4;
     WHENET_REQUIRE(xs == 0 || (xs == 2 && k == 5 && s == 1), WHENET_EINVAL, "front2: the origin shift exists for 5x5 stride-1 layers");
-    WHENET_REQUIRE(TH % RL == 0 && Ho % TH == 0 && OXG % TXG == 0 && (CC % 32 == 0 || CC == Cexp) && Cexp % 16 == 0 &&
+    // (x tiles may be ragged: the last tile of a row then holds fewer output groups; outputs, channel sums and the expand
+    //  strips beyond the image are masked / clipped by the kernel)
+    WHENET_REQUIRE(TH % RL == 0 && Ho % TH == 0 && TXG >= 1 && TXG <= OXG && (CC % 32 == 0 || CC == Cexp) && Cexp % 16 == 0 &&
                        (threads == 256 || threads == 512),
                    WHENET_EINVAL, "front2: bad tile plan");
     Front2Plan p;
@@ -578,7 +580,7 @@ Front2Plan make_front2_plan(int k, int s, int Ho, int Cexp, int CC, int TH, int 
     p.TH = TH;
     p.TXG = TXG;
     p.xs = xs;
-    p.tiles_x = OXG / TXG;
+    p.tiles_x = ceil_div(OXG, TXG);
     p.tiles_y = Ho / TH;
     p.chunks = ceil_div(Cexp, p.CC);
     p.EH = (TH - 1) * s + k;
@@ -631,7 +633,7 @@ std::vector<Front2Plan> plan_front2_candidates(int k, int s, int Ho, int Cexp) {
     for (int CC : {32, 64, 96, 128})
         for (int TH : {7, 14, 28})
             for (int TXG = 1; TXG <= OXG; ++TXG) {
-                if (Ho % TH || OXG % TXG || (CC > Cexp && CC != 32)) continue;
+                if (Ho % TH || (CC > Cexp && CC != 32)) continue;       // (ragged x tiles are candidates too)
                 if (CC < Cexp && Cexp % CC && (Cexp % CC) % 16) continue;
                 if (TXG < 2 && OXG > 1) continue;                        // (x tiles of one group: all halo)
                 for (int xs : {0, 2}) {
