@@ -68,12 +68,13 @@ struct F2Params {
 template <bool EDGE>
 __device__ __forceinline__ void expand_store(const float16v& acc, float bias, unsigned char* ep, const int (&eoff)[4],
                                              const int (&drd)[4], const int (&dcd)[4], int nr_left, int ng_left) {
-    const float2v b2 = {bias, bias};
+    (void)bias;                                    // (round 4: the BN bias is the accumulators' initial value -- one v_pk_add per two
+                                                   //  values less in a VALU-bound epilogue)
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
         if (!EDGE || (drd[qq] < nr_left && dcd[qq] < ng_left)) {
-            const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]} + b2);
-            const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]} + b2);
+            const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]});
+            const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]});
             half4 o;
             o[0] = half_t(y0[0]);
             o[1] = half_t(y0[1]);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         if (t >= t_end) break;                                 // (uniform)
         float16v acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = bias_cur;        // (this lane's channel: BN bias as the initial value)
 #pragma unroll
         for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[u], acc, 0, 0, 0);
 #pragma unroll
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         const unsigned char* bp = E + c * CP + ((c >> 3) & 1) * 8 + (seg * RL * S) * RP + xgl * (8 * S);
         float4v acc[RL];
 #pragma unroll
-        for (int r = 0; r < RL; ++r) acc[r] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < RL; ++r) acc[r] = float4v{bdv, bdv, bdv, bdv};          // (BN bias as the initial value)
 #pragma unroll
         for (int er = 0; er < NER; ++er) {
             half4 bv[NCH];
@@ -387,7 +388,6 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
                 }
             }
         }
-        const float bd_this = bdv;
         const int cb_this = cb, cq_this = cq;
         if (++cq == ncq) {                                     // the next block's taps travel during the epilogue
             cq = 0;
@@ -408,15 +408,15 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         const unsigned obase = (__umul24(unsigned(oy0 + segP * RL + rP), unsigned(p.Ho)) + unsigned(oxP)) * unsigned(p.Cexp) * 2u +
                                unsigned(c0 + cb_this * 16 + hP * 8) * 2u;
         float2v sum2 = {0.f, 0.f};
-        const float2v m01 = {m[0], m[1]}, m23 = {m[2], m[3]}, bd2 = {bd_this, bd_this};
+        const float2v m01 = {m[0], m[1]}, m23 = {m[2], m[3]};
         unsigned char* sw = stg + j * 32 + cl * 2;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                 // rows 0..3, then rows 4..6, through the 2 KB stage
             const int r0 = half * 4, nr = half ? 3 : 4;
 #pragma unroll
             for (int r = 0; r < nr; ++r) {
-                const float2v y01 = swish2(float2v{acc[r0 + r][0], acc[r0 + r][1]} + bd2);
-                const float2v y23 = swish2(float2v{acc[r0 + r][2], acc[r0 + r][3]} + bd2);
+                const float2v y01 = swish2(float2v{acc[r0 + r][0], acc[r0 + r][1]});
+                const float2v y23 = swish2(float2v{acc[r0 + r][2], acc[r0 + r][3]});
                 sum2 = y01 * m01 + sum2;
                 sum2 = y23 * m23 + sum2;
                 *reinterpret_cast<half_t*>(sw + (r * 4 + 0) * 128) = half_t(y01[0]);

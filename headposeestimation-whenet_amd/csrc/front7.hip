@@ -143,11 +143,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
             if (t < t_lo || t >= t_hi) continue;               // (uniform)
             float16v acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[r] = bias_t[t];   // (BN bias as the accumulators' initial value)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], Wl[(ks * NT + t) * 64 + lane], acc, 0, 0, 0);
-            const float2v b2 = {bias_t[t], bias_t[t]};
             const int ch = t * 32 + lm, cb = ch >> 4, cl = ch & 15;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
@@ -155,8 +154,8 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
                 if (R < nrow) {
                     const int cr = (R * 37) >> 8, row = R - cr * 7;
                     const int jq = cr >> 2, j = cr & 3;
-                    const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]} + b2);
-                    const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]} + b2);
+                    const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]});
+                    const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]});
                     half4 o;
                     o[0] = half_t(y0[0]);
                     o[1] = half_t(y0[1]);
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
         const unsigned char* bp = E + ((((jq * NCB + cb) * ROWS) * 64 + unit) << 4);
         float4v acc[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[r] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < ROWS; ++r) acc[r] = float4v{bdv, bdv, bdv, bdv};        // (BN bias as the initial value)
 #pragma unroll
         for (int er = 0; er < ROWS; ++er) {
             const half8 v = *reinterpret_cast<const half8*>(bp + er * 1024);
@@ -237,7 +236,6 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
                 }
             }
         }
-        const float bd_this = bdv;
         if (it + NWAVE < nitem) load_taps(it + NWAVE);         // the next item's taps travel during the epilogue
         // ---- BN + Swish, per-crop channel sums, and the way out: lane (channel cl, crop j) holds 7 rows x 4 pixels -----
         const int cr = jq * 4 + j;                             // crop of the group
@@ -250,15 +248,15 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
         const unsigned obase = (unsigned(crop0 + crP) * 49u + unsigned(rP) * 7u + unsigned(oxP)) * unsigned(p.Cexp) * 2u +
                                unsigned(c0 + cb * 16 + hP * 8) * 2u;
         float2v sum2 = {0.f, 0.f};
-        const float2v m01 = {m[0], m[1]}, m23 = {m[2], m[3]}, bd2 = {bd_this, bd_this};
+        const float2v m01 = {m[0], m[1]}, m23 = {m[2], m[3]};
         unsigned char* sw = stg + j * 32 + cl * 2;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                 // rows 0..3, then rows 4..6, through the 2 KB stage
             const int r0 = half * 4, nr = half ? 3 : 4;
 #pragma unroll
             for (int r = 0; r < nr; ++r) {
-                const float2v y01 = swish2(float2v{acc[r0 + r][0], acc[r0 + r][1]} + bd2);
-                const float2v y23 = swish2(float2v{acc[r0 + r][2], acc[r0 + r][3]} + bd2);
+                const float2v y01 = swish2(float2v{acc[r0 + r][0], acc[r0 + r][1]});
+                const float2v y23 = swish2(float2v{acc[r0 + r][2], acc[r0 + r][3]});
                 sum2 = y01 * m01 + sum2;
                 sum2 = y23 * m23 + sum2;
                 *reinterpret_cast<half_t*>(sw + (r * 4 + 0) * 128) = half_t(y01[0]);
@@ -603,8 +601,11 @@ Front7Plan make_front7_plan(int dtype, int Cin, int Cexp, int G, int CC, int thr
     const int njq = (G + 3) / 4, ncb = CC / 16, ks = Cin / (f32 ? 8 : 16), nt = CC / 32;
     const size_t e_bytes = size_t(njq) * ncb * HW7 * 64 * (f32 ? 32 : 16);
     p.off_w = int(e_bytes);
-    p.off_stage = p.off_w + ks * nt * 1024;
-    p.off_red = p.off_stage + (f32 ? 0 : (threads / 64) * 2048);     // (the f32 kernel stores its outputs directly)
+    // f16: the output stage (2 KB per wave) ALIASES the weight region -- the staged weights are dead once the expand phase is
+    // over, and a workgroup barrier separates the phases; the f32 kernel stores its outputs directly
+    const int w_bytes = ks * nt * 1024, stage_bytes = f32 ? 0 : (threads / 64) * 2048;
+    p.off_stage = p.off_w;
+    p.off_red = p.off_w + (w_bytes > stage_bytes ? w_bytes : stage_bytes);
     p.off_sum = p.off_red + G * 2 * CC * 4;
     p.lds_bytes = size_t(p.off_sum) + size_t(G) * CC * 4;
     return p;

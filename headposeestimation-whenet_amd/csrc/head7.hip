@@ -97,16 +97,15 @@ __global__ __launch_bounds__(NTHR) void whenet_head7_kernel(const half_t* __rest
             if (t < t_lo || t >= t_hi) continue;               // (uniform)
             float16v acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[r] = bias_t[t];   // (BN bias as the accumulators' initial value)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], Wl[(ks * NT + t) * 64 + lane], acc, 0, 0, 0);
-            const float2v b2 = {bias_t[t], bias_t[t]};
             float sum = 0.f;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]} + b2);
-                const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]} + b2);
+                const float2v y0 = swish2(float2v{acc[4 * qq], acc[4 * qq + 1]});
+                const float2v y1 = swish2(float2v{acc[4 * qq + 2], acc[4 * qq + 3]});
                 const float y[4] = {y0[0], y0[1], y1[0], y1[1]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
