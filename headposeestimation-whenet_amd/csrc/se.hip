@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256) void whenet_se_excite_kernel(const float* __re
                                                                const float* __restrict__ b2, void* __restrict__ gate,
                                                                int C, int R, int SPLIT, int gate_f16) {
     constexpr int NTHR = 256;
-    constexpr int NCI = 2;                            // channels per lane (slice <= 512)
+    // channels per lane.  RP = 48 (C = 1152): ONE channel per lane (8 slices per crop) -- with two, the excite rows alone are 96
+    // registers and the kernel needs 121: under the 3-forward load it then cannot share a SIMD with the four 104-register waves
+    // of block 2's fused kernel (512 - 4 x 104 = 96 registers are free) and waits for a workgroup of theirs to retire: 11 us
+    // per launch under load against 4.8 us alone, while the 88-register RP = 28 instantiation stays at 4.9 us (round 4).
+    constexpr int NCI = (RP >= 48) ? 1 : 2;
     __shared__ float s_r[RP];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / SPLIT, slice = blockIdx.x - b * SPLIT;
@@ -239,9 +243,9 @@ void launch_rp(const SeArgs& a, hipStream_t stream) {
 
 int se_padded_r(int R) { return (R + 3) & ~3; }
 
-// excite workgroups per crop: a 256-lane workgroup covers <= 512 channels, and wide layers are
-// split further so that no CU streams more than ~64 KB of excite kernel
-int se_excite_split(int C) { return C > 768 ? 4 : (C > 288 ? 2 : 1); }
+// excite workgroups per crop: a 256-lane workgroup covers <= 512 channels (two per lane; ONE per lane for C > 768: see the
+// kernel), and wide layers are split further so that no CU streams more than ~64 KB of excite kernel
+int se_excite_split(int C) { return C > 768 ? 8 : (C > 288 ? 2 : 1); }
 
 void launch_se_excite(const SeExciteArgs& a, hipStream_t stream) {
     WHENET_REQUIRE(a.C <= 1152 && a.np >= 1, WHENET_EINVAL, "squeeze-excite: bad shape");
