@@ -24,16 +24,19 @@ the K-step region is repeated (each repeat again bracketed by sync + barrier) un
 `ms_per_step` / `value` are the MEDIAN repeat, every repeat is listed in `repeats_ms_per_step` (`steps` stays K).
 
 Extra objects on the line:
-  sweep         the other north-star batch sizes in f16 -- 1, 8, 512 crops per step -- ~0.1 s each: `value` (3 forwards in
-                flight), `value_serial`, and the dominant kernel's roofline fraction at that batch
-  roofline      dominant kernel: algorithmic bytes / HIP-event duration, per launch
+  sweep         the other north-star batch sizes in f16 -- 1, 8, 512 crops per step -- and the f32 parity configuration at batch
+                64 (`f32_b64`), ~0.1 s each: `value` (3 forwards in flight), `value_serial`, and the dominant kernel's roofline
+                fraction at that batch (for the crops per launch whenet_profile() reports)
+  roofline      dominant kernel: algorithmic bytes / HIP-event duration, per launch; `traffic` = PMC FETCH_SIZE + WRITE_SIZE per launch
+                from the committed set collected at the SAME crops per launch (profiles/rNN/pmc_traffic_*.json; null otherwise)
                 (whenet_profile(): one event between consecutive launches on the chain's
                 stream, ONE forward of the batch alone on the GPU, eager pass run right after
                 the timed region -- the figures rocprofv3's kernel trace also reports, since
                 tracing serialises the overlapped forwards) vs 8 TB/s HBM
   cpu_baseline  the float32 torch-CPU restatement of the reference path ("port": the true
                 Keras path cannot run here), timed on this box's host cores (P pinned processes x T threads
-                covering half of the logical CPUs, `cores` = P*T), rank 0, N=1
+                covering half of the logical CPUs; `cores` = what the run could use: min(threads launched, cgroup CPU quota,
+                measured parallelism), `threads_launched` = P*T), rank 0, N=1
   latency_b1    configs[1]: batch=1 fp32 single-crop latency (median / p99), N=1 only
   frame_pipeline  configs[4]: one video frame + k head boxes per submission (PCIe included), N=1 only
   pcie_inclusive  the host-pointer forms on the same batch, H2D + D2H included (never `value`)

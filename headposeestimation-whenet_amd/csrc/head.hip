@@ -151,13 +151,17 @@ __device__ __forceinline__ void st_l2_f32(float* p, float v) {
 
 // FEAT_IN: x is the pooled feature vector [n][1280] f32 (head7.hip pooled it), not the head conv's output tensor
 template <typename T, bool FEAT_IN>
-__global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(FEAT_IN ? 256 : 512) void whenet_heads_split_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bvec,
                                                                 float* __restrict__ logits_out, float* __restrict__ ypr,
                                                                 int32_t* __restrict__ amax, float* __restrict__ part,
                                                                 unsigned* __restrict__ count) {
-    constexpr int NW = 8, GP = 6;                         // 6 position groups in the pooling
-    __shared__ float s_gap[GP][HCH];
+    // FEAT_IN: 4 waves (no pooling to spread): a 256-lane workgroup of 64 registers shares a SIMD with the four 104-register
+    // waves of block 2's fused kernel under the 3-forward load; the 8-wave form needs two such waves per SIMD and waits
+    constexpr int NTHR = FEAT_IN ? 256 : 512, NW = NTHR / 64, GP = 6;      // 6 position groups in the pooling
+    // (FEAT_IN: no pooling scratch -- 9.5 instead of 17 KB of LDS, so that under the 3-forward load a workgroup fits beside the
+    //  two 75 KB workgroups of block 2's fused kernel on a CU instead of waiting for one of them to retire)
+    __shared__ float s_gap[FEAT_IN ? 1 : GP][FEAT_IN ? 4 : HCH];
     __shared__ float s_feat[HCH];
     __shared__ float s_part[NW][N_LOGITS + 4];
     __shared__ float s_logit[N_LOGITS + 4];
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(512) void whenet_heads_split_kernel(const T* __rest
 
     // ---- GAP over the 49 positions for this workgroup's channels: lane <-> (4 channels, positions p = grp mod 6)
     if constexpr (FEAT_IN) {
-        if (tid < HCH) s_feat[tid] = reinterpret_cast<const float*>(x)[size_t(b) * FEAT + q * HCH + tid];
+        for (int c = tid; c < HCH; c += NTHR) s_feat[c] = reinterpret_cast<const float*>(x)[size_t(b) * FEAT + q * HCH + c];
     } else {
         using V4 = T __attribute__((ext_vector_type(4)));
         const T* xb = x + size_t(b) * HW * FEAT + q * HCH;
@@ -295,7 +299,7 @@ void launch_heads_split(const HeadsArgs& a, float* part, unsigned* count, int dt
     WHENET_REQUIRE((a.x != nullptr || a.feat_in != nullptr) && part != nullptr && count != nullptr, WHENET_EINVAL,
                    "heads (split): missing buffers");
     if (a.feat_in != nullptr)
-        hipLaunchKernelGGL((whenet_heads_split_kernel<float, true>), dim3(HSPLIT, a.n), dim3(512), 0, stream, a.feat_in, a.w, a.b,
+        hipLaunchKernelGGL((whenet_heads_split_kernel<float, true>), dim3(HSPLIT, a.n), dim3(256), 0, stream, a.feat_in, a.w, a.b,
                            a.logits, a.ypr, a.argmax, part, count);
     else if (dtype == WHENET_F16)
         hipLaunchKernelGGL((whenet_heads_split_kernel<half_t, false>), dim3(HSPLIT, a.n), dim3(512), 0, stream,
