@@ -30,6 +30,7 @@
 #include "device_math.h"
 #include "kernels.h"
 #include "se_device.h"
+#include "stamps.h"
 
 namespace whenet {
 
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     const int nch = q % NCH;
     const int mt = (id & 7) + 8 * (q / NCH);
     if (mt >= MT) return;
+    STAMP(0);
 
     const int lane = threadIdx.x & 63;
     const int kpart = threadIdx.x >> 6;
@@ -150,12 +152,14 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     issue(kpart, o0);
     if constexpr (GM == 1) lds_barrier();           // the staged gate is complete (its global loads were issued first)
     if constexpr (GM == 2) se_fused_to_lds<T, 256>(se, crop_lo, ncrop, K, s_gate, s_r);    // (operands already in flight)
+    STAMP(1);
     for (int ks = kpart; ks < KS; ks += 2 * U * SK) {
         issue(ks + U * SK, o1);
         compute(o0, ks);
         issue(ks + 2 * U * SK, o0);
         if (ks + U * SK < KS) compute(o1, ks + U * SK);
     }
+    STAMP(2);
 
     // ---- combine: wave p owns accumulators [p*SL, (p+1)*SL) of the flattened (mb, t, r) index -----
     const int f0 = kpart * SL;                       // first flattened accumulator of this wave's slice
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
         }
     }
     lds_barrier();
+    STAMP(3);
     float sum[SL];
 #pragma unroll
     for (int src = 0; src < 4; ++src) {
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
         }
         *reinterpret_cast<OT*>(out + size_t(own_row) * N + n0) = o;
     }
+    STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------
