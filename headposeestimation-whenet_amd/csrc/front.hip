@@ -492,13 +492,16 @@ std::vector<FrontPlan> plan_front_candidates(int dtype, int k, int s, int H, int
 }
 
 namespace {
-// Plans measured on MI355X for EfficientNet-B0's fifteen f16 layer shapes (tools/probes/
+// Plans measured on MI355X for EfficientNet-B0's fifteen layer shapes, f16 (round 1) and f32 (round 4) (tools/probes/
 // front_tune.hip: every candidate timed at 64 and 16 crops per launch; profiles/r01/
 // front_tune_f16.txt).  The a-priori score above ranks candidates of one layer in roughly the
 // right order but cannot see tail quantisation or the per-workgroup fixed costs.
 struct TunedPlan { int k, s, H, Cexp, CC, TH, NSX, pad; };
 const TunedPlan TUNED_F16[] = {
 #include "front_tuned_f16.inc"
+};
+const TunedPlan TUNED_F32[] = {
+#include "front_tuned_f32.inc"
 };
 }  // namespace
 
@@ -507,11 +510,16 @@ FrontPlan plan_front(int dtype, int k, int s, int H, int Ho, int Cexp) {
     const std::vector<FrontPlan> cand = plan_front_candidates(dtype, k, s, H, Ho, Cexp, &scores);
     WHENET_REQUIRE(!cand.empty(), WHENET_EINVAL, "front: no tile plan fits");
     static const bool no_tuned = getenv("WHENET_FRONT_NO_TUNED") != nullptr;       // (probes only; read once)
-    if (dtype == WHENET_F16 && !no_tuned) {
-        for (const TunedPlan& t : TUNED_F16)
+    if (!no_tuned) {
+        const bool f16 = dtype == WHENET_F16;
+        const TunedPlan* tb = f16 ? TUNED_F16 : TUNED_F32;
+        const size_t nt = f16 ? sizeof(TUNED_F16) / sizeof(TunedPlan) : sizeof(TUNED_F32) / sizeof(TunedPlan);
+        for (size_t i = 0; i < nt; ++i) {
+            const TunedPlan& t = tb[i];
             if (t.k == k && t.s == s && t.H == H && t.Cexp == Cexp)
                 for (const FrontPlan& p : cand)
-                    if (p.CC == t.CC && p.TH == t.TH && p.NSX == t.NSX && p.EP == t.CC * 2 + t.pad) return p;
+                    if (p.CC == t.CC && p.TH == t.TH && p.NSX == t.NSX && p.EP == t.CC * (f16 ? 2 : 4) + t.pad) return p;
+        }
     }
     size_t best = 0;
     for (size_t i = 1; i < cand.size(); ++i)

@@ -32,6 +32,10 @@
 #include "se_device.h"
 #include "stamps.h"
 
+#ifndef WHENET_PW_DEPTH
+#define WHENET_PW_DEPTH 2       // operand groups a split-K wave keeps in flight (probes build other depths)
+#endif
+
 namespace whenet {
 
 namespace {
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     STAMP(0);
 
     const int lane = threadIdx.x & 63;
-    const int kpart = threadIdx.x >> 6;
+    const int kpart = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nt0 = nch * NT;
     const int g = lane >> 5;
     bool rvalid[MB];
@@ -98,11 +102,17 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     }
     const int row_last = (row_first + MB * 32 < M ? row_first + MB * 32 : M) - 1;
     const int ncrop = row_last / HW - crop_lo + 1;                     // <= GCROPS
+    // gate rows of crops crop_lo .. crop_hi -> LDS, 16 bytes per lane (K is a multiple of 16): all loads issued at once, in front
+    // of the first operand group, written to LDS once that group is on its way as well
+    constexpr int GV = GM == 1 ? (GCROPS * GK / V + 255) / 256 : 1;
+    VT gv[GV];
     if constexpr (GM == 1) {
-        // gate rows of crops crop_lo .. crop_hi -> LDS, 16 bytes per lane (K is a multiple of 16)
         const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
-        VT* dst = reinterpret_cast<VT*>(s_gate);
-        for (int i = threadIdx.x; i < ncrop * K / V; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            const int i = int(threadIdx.x) + j * 256;
+            gv[j] = src[i < ncrop * K / V ? i : 0];
+        }
     }
     const VT* wp = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64 + lane;
 
@@ -117,47 +127,59 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     struct Ops {
         VT a[U][MB], w[U][NT];
     };
+    // Every load of the k-loop is UNCONDITIONAL (addresses clamped to the last k-step / tile / row; the MFMAs of a k-step past
+    // KS or of a tile past NTILES are skipped by wave-uniform branches, rows past M are never stored): with loads under
+    // per-lane or per-group conditions the compiler cannot count what is outstanding and waits with vmcnt(0) -- for the group
+    // it has just issued as well, which serialises the "next group in flight" the loop is written for (round 4, from the ISA).
     auto issue = [&](int ks, Ops& o) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k1 = ks + u * SK;
-            const bool ok = k1 < KS;                                   // (wave-uniform)
-            const VT* wk = wp + size_t(k1) * NTILES * 64;
+            const int k1c = k1 < KS ? k1 : KS - 1;                     // (wave-uniform)
+            const VT* wk = wp + size_t(k1c) * NTILES * 64;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) o.w[u][t] = (ok && nt0 + t < NTILES) ? wk[t * 64] : vec_zero<T>();
+            for (int t = 0; t < NT; ++t) o.w[u][t] = wk[(nt0 + t < NTILES ? t : 0) * 64];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const bool la = ok && rvalid[mb] && k1 * 2 * V + g * V < K;
-                o.a[u][mb] = la ? *reinterpret_cast<const VT*>(ap[mb] + k1 * 2 * V) : vec_zero<T>();
-            }
+            for (int mb = 0; mb < MB; ++mb) o.a[u][mb] = *reinterpret_cast<const VT*>(ap[mb] + k1c * 2 * V);
         }
     };
     auto compute = [&](const Ops& o, int ks) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            const int k1 = ks + u * SK;
+            if (k1 >= KS) continue;                                    // (wave-uniform)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 VT a = o.a[u][mb];
-                if constexpr (GATE) {                                      // (rows past M / k past K: a is zero)
-                    const int k1 = ks + u * SK;
-                    if (k1 < KS) a = a * *reinterpret_cast<const VT*>(gp[mb] + k1 * 2 * V);
-                }
+                if constexpr (GATE) a = a * *reinterpret_cast<const VT*>(gp[mb] + k1 * 2 * V);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     if (nt0 + t < NTILES) Mfma<T>::step(o.w[u][t], a, acc[mb][t]);
             }
+        }
     };
 
-    Ops o0, o1;
-    issue(kpart, o0);
-    if constexpr (GM == 1) lds_barrier();           // the staged gate is complete (its global loads were issued first)
+    constexpr int D = WHENET_PW_DEPTH;              // operand groups in flight per wave
+    Ops o[D];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(kpart + d * U * SK, o[d]);
+    if constexpr (GM == 1) {
+        VT* dst = reinterpret_cast<VT*>(s_gate);
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            const int i = int(threadIdx.x) + j * 256;
+            if (i < ncrop * K / V) dst[i] = gv[j];
+        }
+        lds_barrier();
+    }
     if constexpr (GM == 2) se_fused_to_lds<T, 256>(se, crop_lo, ncrop, K, s_gate, s_r);    // (operands already in flight)
     STAMP(1);
-    for (int ks = kpart; ks < KS; ks += 2 * U * SK) {
-        issue(ks + U * SK, o1);
-        compute(o0, ks);
-        issue(ks + 2 * U * SK, o0);
-        if (ks + U * SK < KS) compute(o1, ks + U * SK);
+    for (int ks = kpart; ks < KS; ks += D * U * SK) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            issue(ks + (d + D - 1) * U * SK, o[(d + D - 1) % D]);
+            compute(o[d], ks + d * U * SK);
+        }
     }
     STAMP(2);
 
@@ -527,6 +549,7 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
     }
     const PwChoice ch = choose_pw(a, num_cus);
     if (ch.kind == 1) {
+        WHENET_REQUIRE(a.K % (2 * Vec<T>::V) == 0, WHENET_EINVAL, "pointwise: a deep contraction is a whole number of k-steps");
         if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, GM, RES, ACT>(a, stream);
         else launch_splitk<T, 1, GM, RES, ACT>(a, stream);
         return;

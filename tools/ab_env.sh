@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of an environment variable: tools/ab_env.sh VAR v1 v2 ...  -> value / serial / chain and the per-layer table
+# A/B of an environment variable: [AB_BENCH_ARGS="--dtype f32"] tools/ab_env.sh VAR v1 v2 ...  -> value / serial / chain and the per-layer table
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 VAR=$1; shift; i=0
 for v in "$@"; do
   i=$((i+1))
-  env $VAR=$v timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency --no-sweep --dump-layers gpurun_out/abe_layers_$i.json > gpurun_out/abe_bench_$i.json 2>/dev/null
+  env $VAR=$v timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency --no-sweep $AB_BENCH_ARGS --dump-layers gpurun_out/abe_layers_$i.json > gpurun_out/abe_bench_$i.json 2>/dev/null
   python - gpurun_out/abe_bench_$i.json "$VAR=$v" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
