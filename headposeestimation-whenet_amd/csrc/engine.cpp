@@ -616,6 +616,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
     if (fuse_head) {
         // head conv + GlobalAveragePooling2D as one kernel (head7.hip): v.hc receives the pooled features [n][1280] f32
         Head7Args a{};
+        a.dtype = dtype_;
         a.x = cur;
         a.wep = head_.wp;
         a.bias = head_.bias;
@@ -624,7 +625,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.N = head_.N;
         a.NTILES = head_.NTILES;
         a.n = n;
-        R("head", "pw", kernel_name_head7(n).c_str(), double(n) * (49.0 * a.K * es + a.N * 4.0), 2.0 * n * 49.0 * a.K * a.N,
+        R("head", "pw", kernel_name_head7(dtype_, n).c_str(), double(n) * (49.0 * a.K * es + a.N * 4.0), 2.0 * n * 49.0 * a.K * a.N,
           [&] { launch_head7(a, s); });
         HeadsArgs hargs{};
         hargs.feat_in = reinterpret_cast<const float*>(v.hc);

@@ -176,7 +176,7 @@ class Engine {
     int front_impl_ = 1;        // option "front_impl": 0 = front.hip everywhere, 1 = per layer (f16: front2.hip where it is
                                 // the faster kernel), 2 = front2.hip everywhere (f16)
     bool poison_ = false;       // debug option "poison": NaN-fill the activation arena before every forward
-    bool head_fuse_ = true;     // option "head_fuse": f16 -- the head conv pools its own output (head7.hip); 0 = round 3's two stages
+    bool head_fuse_ = true;     // option "head_fuse": the head conv pools its own output (head7.hip, f16 and f32); 0 = round 3's two stages
     bool front7_ = true;        // option "front7": blocks 13-16 of an f16 handle run front7.hip (a group of crops per workgroup)
                                 // when front_impl = 1; 0 = the per-layer choice of round 3 (front.hip there)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)

@@ -94,6 +94,7 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
     HeadsArgs h{};
     if (fuse_head) {          // the forward's form: head conv + pooling as one kernel (head7.hip), Dense heads on its features
         Head7Args a{};
+        a.dtype = dtype_;
         a.x = x0_;
         a.wep = head_.wp;
         a.bias = head_.bias;

@@ -1,4 +1,4 @@
-// Head conv fused with GlobalAveragePooling2D, f16 (round 4): Conv2D(320 -> 1280, 1x1, no bias) + BN + Swish on the 7 x 7 map,
+// Head conv fused with GlobalAveragePooling2D (round 4; f16, and f32 further down): Conv2D(320 -> 1280, 1x1, no bias) + BN + Swish on the 7 x 7 map,
 // then the mean over the 49 positions -- the 1280 pooled features per crop are all that leaves the kernel.
 //
 // Reference: efficientnet 0.0.4's head conv (the last layer of EfficientNetB0(include_top=False), /root/reference/whenet.py:8)
@@ -131,6 +131,113 @@ __global__ __launch_bounds__(NTHR) void whenet_head7_kernel(const half_t* __rest
     }
 }
 
+// ---- f32 (the parity configuration) ---------------------------------------------------------------------------------------
+// The same decomposition on v_mfma_f32_32x32x2_f32 (exact f32 products, 64 cycles per instruction: this kernel is bound by
+// the matrix pipe, 64 crops x 64 rows x 320 x 1280 MACs = 21 us at the 157 TF peak).  A workgroup owns G crops x ONE 32-channel
+// tile (40 KB of weights in LDS, 40 k-steps of 8); wave = strip; the strip's activation rows are streamed in groups of 5 k-steps
+// (one 16-byte load per lane and k-step: 4 consecutive k of the lane's pixel row, element t feeds the t-th instruction, as
+// pw.hip), the next group in flight while the current one multiplies; every load is unconditional (clamped addresses) so that
+// the waits are counted.  Epilogue, pooling order and the batch-invariance argument are the f16 kernel's.
+// Round 3/4's f32 path until now: the split-K GEMM wrote the 49 x 1280 f32 tensor (16 MB per 64 crops) and the heads kernel
+// read it back: 50 + 15 us per 64 crops.
+constexpr int H7F_KS = H7_K / 8, H7F_NC = 32, H7F_KG = 5, H7F_NGRP = H7F_KS / H7F_KG;
+
+template <int G>
+__global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* __restrict__ x, const float* __restrict__ wep,
+                                                                   const float* __restrict__ bias, float* __restrict__ feat, int n,
+                                                                   int NTILES, int N) {
+    constexpr int NTHR = 128 * G, nstrip = 2 * G, KS = H7F_KS, NC = H7F_NC, KG = H7F_KG, NGRP = H7F_NGRP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float4v* Wl = reinterpret_cast<const float4v*>(smem);                 // [KS][64 lanes]
+    float* s_gap = reinterpret_cast<float*>(smem + KS * 1024);                  // [nstrip][2 (g)][NC]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int strip = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, lm = lane & 31;
+    const int c0 = blockIdx.x * NC;
+    const int crop0 = blockIdx.y * G;
+
+    constexpr int nwv = KS * 64;
+    static_assert(nwv % NTHR == 0, "weight staging: whole vectors per lane");
+    constexpr int WV = nwv / NTHR;
+    float4v wstage[WV];
+    {
+        const float4v* src = reinterpret_cast<const float4v*>(wep);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * NTHR;
+            wstage[i] = src[(size_t(v >> 6) * NTILES + (c0 >> 5)) * 64 + (v & 63)];
+        }
+    }
+    int gc = crop0 + (strip >> 1);
+    gc = gc < n - 1 ? gc : n - 1;
+    int pxl = (strip & 1) * 32 + lm;
+    pxl = pxl < H7_HW ? pxl : H7_HW - 1;                        // (idle rows: any valid address, masked out of the sum)
+    const float* xr = x + (size_t(gc) * H7_HW + pxl) * H7_K + g * 4;
+    float4v a0[KG], a1[KG];
+    auto load_group = [&](float4v (&a)[KG], int grp) {
+#pragma unroll
+        for (int u = 0; u < KG; ++u) a[u] = *reinterpret_cast<const float4v*>(xr + (grp * KG + u) * 8);
+    };
+    load_group(a0, 0);
+    const float bias_v = bias[c0 + lm];
+    {
+        float4v* dst = reinterpret_cast<float4v*>(smem);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) dst[tid + i * NTHR] = wstage[i];
+    }
+    lds_barrier();
+
+    float16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto compute = [&](const float4v (&a)[KG], int grp) {
+#pragma unroll
+        for (int u = 0; u < KG; ++u) {
+            const float4v w = Wl[(grp * KG + u) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], w[t], acc, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int grp = 0; grp < NGRP; grp += 2) {                  // (the scheduling barriers keep a whole group in flight: left to
+        load_group(a1, grp + 1);                               //  itself the scheduler sinks every load to one k-step ahead of its use)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a0, grp);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp + 2 < NGRP) load_group(a0, grp + 2);           // (compile time)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a1, grp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int px = (strip & 1) * 32 + 8 * (r >> 2) + 4 * g + (r & 3);      // this value's pixel of the crop
+        const float y = conv_swish<float>(acc[r] + bias_v);
+        sum += (px < H7_HW) ? y : 0.f;
+    }
+    s_gap[(strip * 2 + g) * NC + lm] = sum;
+    lds_barrier();
+    // ---- mean over the 49 positions, fixed order ---------------------------------------------------------------------------
+    if (tid < G * NC) {
+        const int cr = tid / NC, c = tid % NC;
+        if (crop0 + cr < n && c0 + c < N) {
+            const float* s0 = s_gap + ((2 * cr) * 2) * NC + c;
+            feat[size_t(crop0 + cr) * N + c0 + c] = ((s0[0] + s0[NC]) + (s0[2 * NC] + s0[3 * NC])) * (1.0f / 49.0f);
+        }
+    }
+}
+
+template <int G>
+void launch_h7_f32(const Head7Args& a, hipStream_t stream) {
+    const size_t lds = size_t(H7F_KS) * 1024 + size_t(2 * G) * 2 * H7F_NC * 4;
+    hipLaunchKernelGGL((whenet_head7_f32_kernel<G>), dim3(a.N / H7F_NC, ceil_div(a.n, G)), dim3(128 * G), lds, stream,
+                       static_cast<const float*>(a.x), static_cast<const float*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N);
+    WHENET_HIP_CHECK(hipGetLastError());
+}
+
 template <int G>
 void launch_h7(const Head7Args& a, hipStream_t stream) {
     constexpr int NTHR = 512;
@@ -142,17 +249,27 @@ void launch_h7(const Head7Args& a, hipStream_t stream) {
 
 }  // namespace
 
-bool head7_supported(int dtype, int K, int N, int HW) { return dtype == WHENET_F16 && K == H7_K && HW == H7_HW && N % H7_NC == 0; }
+bool head7_supported(int dtype, int K, int N, int HW) {
+    return (dtype == WHENET_F16 || dtype == WHENET_F32) && K == H7_K && HW == H7_HW && N % H7_NC == 0;
+}
 
 // groups of 4 crops (8 strips = the 8 waves) from 17 crops per launch up, of 2 below (as front7.hip; the group size changes no
 // bit of a crop's features)
 void launch_head7(const Head7Args& a, hipStream_t stream) {
-    WHENET_REQUIRE(head7_supported(WHENET_F16, a.K, a.N, 49) && a.n >= 1 && a.x && a.wep && a.bias && a.feat, WHENET_EINVAL,
-                   "head7: the 320 -> N (multiple of 64) head conv on 7 x 7 maps, f16");
-    if (a.n <= 16) launch_h7<2>(a, stream);
-    else launch_h7<4>(a, stream);
+    WHENET_REQUIRE(head7_supported(a.dtype, a.K, a.N, 49) && a.n >= 1 && a.x && a.wep && a.bias && a.feat, WHENET_EINVAL,
+                   "head7: the 320 -> N (multiple of 64) head conv on 7 x 7 maps");
+    if (a.dtype == WHENET_F16) {
+        if (a.n <= 16) launch_h7<2>(a, stream);
+        else launch_h7<4>(a, stream);
+    } else {
+        if (a.n <= 16) launch_h7_f32<2>(a, stream);
+        else launch_h7_f32<4>(a, stream);
+    }
 }
 
-std::string kernel_name_head7(int n) { return std::string("whenet_head7_kernel<") + (n <= 16 ? "2" : "4") + ", 512>"; }
+std::string kernel_name_head7(int dtype, int n) {
+    if (dtype == WHENET_F16) return std::string("whenet_head7_kernel<") + (n <= 16 ? "2" : "4") + ", 512>";
+    return std::string("whenet_head7_f32_kernel<") + (n <= 16 ? "2" : "4") + ">";
+}
 
 }  // namespace whenet

@@ -127,10 +127,11 @@ void launch_heads_split(const HeadsArgs& a, float* part, unsigned* count, int dt
 int heads_split();
 
 // ---- head7.hip --------------------------------------------------------------------------
-// f16: head conv 1x1 (320 -> 1280) + BN + Swish fused with GlobalAveragePooling2D (whenet.py:8-10): only the pooled
+// head conv 1x1 (320 -> 1280) + BN + Swish fused with GlobalAveragePooling2D (whenet.py:8-10), f16 and f32: only the pooled
 // features leave the kernel.  A group of crops per workgroup, every crop on its own two MFMA strips (batch-invariant).
 struct Head7Args {
-    const void* x;         // [n,7,7,K] half
+    int dtype;             // WHENET_F16 / WHENET_F32
+    const void* x;         // [n,7,7,K] T
     const void* wep;       // packed head-conv weights (MFMA fragment order, snapshot.h)
     const float* bias;     // [N]
     float* feat;           // [n][N] pooled features, f32
@@ -138,7 +139,7 @@ struct Head7Args {
 };
 bool head7_supported(int dtype, int K, int N, int HW);
 void launch_head7(const Head7Args& a, hipStream_t stream);
-std::string kernel_name_head7(int n);
+std::string kernel_name_head7(int dtype, int n);
 
 // ---- front.hip --------------------------------------------------------------------------
 // expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).

@@ -115,8 +115,9 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "front7" (0/1, default 1: with front_impl = 1, blocks 13-16 (7 x 7 maps) of an f16 handle run front7.hip -- a GROUP of
  *                  2 or 4 crops per workgroup, the image-only LDS tile, the chunk's expand weights staged once in LDS; the group
  *                  size follows the launch size and changes no bit of a crop's result; 0 = round 3's per-layer choice),
- *          "head_fuse" (0/1, default 1: f16 handles -- the head conv (whenet.py:8, last layer) pools its own output, the
- *                  GlobalAveragePooling2D of whenet.py:10, in one kernel (head7.hip); 0 = conv, then pooling inside the heads kernel),
+ *          "head_fuse" (0/1, default 1: the head conv (whenet.py:8, last layer) pools its own output, the
+ *                  GlobalAveragePooling2D of whenet.py:10, in one kernel (head7.hip; f16, and f32 since round 4b); 0 = conv, then pooling
+ *                  inside the heads kernel),
  *          "fold12" (0/1, default 1: f16 handles whose block 2 runs front2.hip feed that kernel from block 1's depthwise
  *                  output, with block 1's project conv (linear) composed into block 2's expand weights when the
  *                  snapshot is loaded -- one launch and a 112x112x16 round trip through HBM less; 0 = the two convs

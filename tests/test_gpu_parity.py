@@ -292,6 +292,36 @@ def test_head_conv_fused_with_pooling(blob, taps, golden):
         assert not np.array_equal(l0, l21) and np.abs(l0 - l21).max() < 0.5
 
 
+def test_head_conv_fused_with_pooling_f32(blob, taps, golden):
+    """The same fusion for the parity configuration (head7.hip, v_mfma_f32_32x32x2_f32): against the oracle's pooled features at
+    f32 accuracy, against the two-stage form (head_fuse=0: split-K GEMM, 49 x 1280 tensor written, pooled by the heads kernel),
+    and bitwise batch invariance across the group sizes."""
+    x = taps["b16/out"].astype(np.float32)
+    want = taps["head"].mean(axis=(1, 2))
+    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
+        r1 = h.op_head(x)
+        h.set_option("head_fuse", 0)
+        r0 = h.op_head(x)
+        h.set_option("head_fuse", 1)
+        assert not np.array_equal(r1["feat"], r0["feat"]), "head_fuse is not active"
+        assert rel_err(r1["feat"], want) < 2e-6 and rel_err(r0["feat"], want) < 2e-6
+        assert np.abs(r1["feat"] - r0["feat"]).max() < 2e-5
+        assert np.abs(r1["logits"] - taps["logits"]).max() < 2e-3
+        xs = np.concatenate([x] * 11)[:21]
+        big = h.op_head(xs)
+        for i in (0, 1, 15, 16, 17, 20):
+            one = h.op_head(xs[i:i + 1])
+            assert np.array_equal(big["feat"][i], one["feat"][0]) and np.array_equal(big["logits"][i], one["logits"][0]), i
+        crops = np.concatenate([golden["crops"], synth.scene_crops(13, seed=78)])          # 21 crops
+        y21, a21, l21 = h.forward(crops)
+        for lo, hi in ((0, 1), (1, 3), (0, 16), (4, 21), (20, 21)):
+            y, a, l = h.forward(crops[lo:hi])
+            assert np.array_equal(l, l21[lo:hi]) and np.array_equal(y, y21[lo:hi]), (lo, hi)
+        h.set_option("head_fuse", 0)
+        y0, a0, l0 = h.forward(crops)
+        assert np.abs(l0 - l21).max() < 1e-3 and np.abs(y0 - y21).max() < 1e-3
+
+
 def test_decode_kernel(handle):
     """utils.py:7-11 + whenet.py:28-33 on the device vs numpy float64, incl. ties and extremes."""
     rng = np.random.default_rng(5)
