@@ -245,7 +245,11 @@ DwPlan plan_dw(int dtype, int k, int s, int H, int Ho, int C) {
                 if (lds > 64 * 1024) continue;
                 const double lane_use = double(Ho) * NSX * CG / (double(tiles_y) * threads);
                 const double halo = double(TH * s) * (TW * s) / (double(IH) * IW);   // <= 1
-                const double coalesce = (CV * 16 >= 64) ? 1.0 : 0.6 + 0.4 * (CV * 16) / 64.0;
+                double coalesce = (CV * 16 >= 64) ? 1.0 : 0.6 + 0.4 * (CV * 16) / 64.0;
+                // a pixel's channels split over several chunks in pieces shorter than a 128-byte line: every chunk's workgroup
+                // fetches the whole line (round 4, PMC: block 1's f32 depthwise conv -- 32 channels = 128 B per pixel, planned
+                // as 2 chunks of 64 B -- fetched 222 MB per 64 crops for a 103 MB input, L2 hit rate 5 %)
+                if (cvecs / CV > 1 && CV * 16 < 128) coalesce *= 0.5 + 0.5 * (CV * 16) / 128.0;
                 // occupancy: how many waves a CU can hold with this LDS footprint (160 KiB per CU)
                 int blocks_cu = int((160 * 1024) / lds);
                 if (blocks_cu > 8) blocks_cu = 8;
