@@ -372,7 +372,7 @@ SIMDS, SHADER_GHZ = 1024, 2.25
 def swish_counts():
     """Swish evaluations per crop of every launch that carries them, by layer name (algorithmic: no halo recompute)."""
     from whenet_hip import spec
-    out = {"stem": 112 * 112 * 32, "head": 49 * 1280}
+    out = {"stem": 112 * 112 * 32, "head": 49 * 1280, "stem+b1/dw": 2 * 112 * 112 * 32}
     for b in spec.blocks():
         if b.has_expand:
             out[f"b{b.index}/front"] = (b.h_in * b.h_in + b.h_out * b.h_out) * b.cexp

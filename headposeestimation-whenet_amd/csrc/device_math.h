@@ -36,6 +36,15 @@ __device__ __forceinline__ float conv_swish(float x) {
     return swish_f<(WHENET_PRECISE_CONV_SWISH != 0) && sizeof(T) == 4>(x);
 }
 
+// f32 -> f16 of a value the kernel has just computed, as TWO roundings (the f32 result, then binary16), whatever the optimiser
+// would like to fuse.  Left alone it turns half(x * r) into v_fma_mix (one rounding) in some kernels and into v_mul + v_cvt
+// in others, depending on the code around it: 1 value in 20 000 then differs by an ulp.  Kernels whose results must agree
+// bitwise (stem.hip + dw.hip against stemdw.hip) convert through this.
+__device__ __forceinline__ half_t f32_then_f16(float y) {
+    asm volatile("" : "+v"(y));
+    return half_t(y);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
 // loads and stores (s_waitcnt vmcnt(0)), which would stall prefetched operands and output stores
 // at every phase boundary; the kernels that use this barrier exchange data through LDS only.

@@ -207,6 +207,10 @@ void Engine::set_option(const std::string& key, long value) {
         fold12_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "stem_fuse") {
+        stem_fuse_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "poison") {
         poison_ = value != 0;
     } else if (key == "lanes") {
@@ -255,6 +259,7 @@ void Engine::get_info(whenet_info_t* out) const {
             k += bs.se_fused ? 1 : 2;                   // project alone when it computes the gate itself
         }
         if (fold12_active()) k -= 1;                    // block 1's project launch
+        if (stem_fuse_active()) k -= 1;                 // the stem conv runs inside block 1's depthwise kernel
         out->n_kernels_per_forward = k;
     }
     out->macs_per_crop = 384857312;
@@ -383,18 +388,28 @@ bool Engine::fold12_active() const {
            (front_impl_ == 2 || (front_impl_ == 1 && blocks_[1].f2_preferred));
 }
 
-void* Engine::enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec) {
+// The stem's output is read by block 1's depthwise conv only (block 1 has no expand conv and no skip): for f16 handles fed
+// uint8 crops the two are one kernel (stemdw.hip) when block 1's depthwise tile plan is the one that kernel is built for.
+bool Engine::stem_fuse_active() const {
+    if (!(stem_fuse_ && dtype_ == WHENET_F16 && !blocks_.empty())) return false;
+    const DevBlock& b = blocks_[0];
+    return !b.spec.has_expand() && !b.spec.has_skip() &&
+           stemdw_supported(dtype_, b.dw.plan, b.spec.k, b.spec.s, b.spec.h_in, b.spec.cexp());
+}
+
+void* Engine::enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec,
+                             bool b1_dw_done) {
     const bool fold = fold12_active() && first <= 1 && last >= 2;
     for (int i = first; i <= last; ++i) {
         void* nxt = (cur == v.x0) ? v.x1 : v.x0;
-        enqueue_block(blocks_[size_t(i - 1)], v, cur, nxt, n, s, rec, fold && i <= 2 ? i : 0);
+        enqueue_block(blocks_[size_t(i - 1)], v, cur, nxt, n, s, rec, fold && i <= 2 ? i : 0, b1_dw_done && i == 1);
         cur = nxt;
     }
     return cur;
 }
 
 void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                           LaunchRecorder* rec, int fold) {
+                           LaunchRecorder* rec, int fold, bool dw_done) {
     Rec R{rec, s, repeat_};
     const BlockSpec& sp = b.spec;
     const std::string p = "b" + std::to_string(sp.index);
@@ -506,7 +521,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
           2.0 * a.M * a.K * a.N, [&] { launch_pw(a, dtype_, pw_impl_, num_cus_, s); });
         dw_in = v.e;
     }
-    if (!fused) {
+    if (!fused && !dw_done) {
         DwArgs a{};
         a.in = dw_in;
         a.out = fold == 1 ? out : v.d;
@@ -604,13 +619,30 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
                              hipStream_t s, LaunchRecorder* rec, const float* d_in_f32) {
     Rec R{rec, s, repeat_};
     const double es = double(esz());
-    {
+    const bool stemdw = stem_fuse_active() && d_in_f32 == nullptr;
+    if (stemdw) {
+        // stem + block 1's depthwise conv (stemdw.hip): writes what enqueue_block() would have block 1's dw.hip launch write
+        const DevBlock& b1 = blocks_[0];
+        const bool fold = fold12_active() && blocks_.size() >= 2;
+        StemDwArgs a{};
+        a.in = d_in;
+        a.out = fold ? v.x1 : v.d;
+        a.w = d_stem_w_;
+        a.bias = d_stem_b_;
+        a.lut = d_lut_;
+        a.wd = b1.dw.w;
+        a.bd = b1.dw.bias;
+        a.partial = v.partial;
+        a.n = n;
+        R("stem+b1/dw", "stem", kernel_name_stemdw(), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * (10838016.0 + 112.0 * 112 * 9 * 32),
+          [&] { launch_stemdw(a, s); });
+    } else {
         StemArgs a{d_in, v.x0, d_stem_w_, d_stem_b_, d_lut_, n};
         a.in_f32 = d_in_f32;
         R("stem", "stem", kernel_name_stem(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * 10838016.0,
           [&] { launch_stem(a, dtype_, s); });
     }
-    void* cur = enqueue_blocks(1, int(blocks_.size()), v, v.x0, n, s, rec);
+    void* cur = enqueue_blocks(1, int(blocks_.size()), v, v.x0, n, s, rec, stemdw);
     const bool fuse_head = head_fuse_ && pw_impl_ == 0 && split_heads_ && head7_supported(dtype_, head_.K, head_.N, 49) &&
                            partial_per_crop_ >= size_t(heads_split()) * N_LOGITS;
     if (fuse_head) {

@@ -141,9 +141,11 @@ class Engine {
     // fold: 0 = the block as it stands; 1 = block 1 without its project (its depthwise output goes to `out`);
     //       2 = block 2 fed by that output, block 1's project folded into its expand weights (fold12_active())
     void enqueue_block(const DevBlock& b, const View& v, const void* in, void* out, int n, hipStream_t s,
-                       LaunchRecorder* rec, int fold = 0);
+                       LaunchRecorder* rec, int fold = 0, bool dw_done = false);
     // blocks first..last (1-based) as the forward pass runs them; returns the buffer (x0 / x1 of `v`) holding the result
-    void* enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec);
+    void* enqueue_blocks(int first, int last, const View& v, void* cur, int n, hipStream_t s, LaunchRecorder* rec,
+                         bool b1_dw_done = false);
+    bool stem_fuse_active() const;
     bool fold12_active() const;
     struct BlockSchedule {     // which kernels a block runs under the current options
         bool fused = false, use_f2 = false, use_f7 = false, se_in_front = false, se_fused = false;
@@ -179,6 +181,7 @@ class Engine {
     bool head_fuse_ = true;     // option "head_fuse": the head conv pools its own output (head7.hip, f16 and f32); 0 = round 3's two stages
     bool front7_ = true;        // option "front7": blocks 13-16 of an f16 handle run front7.hip (a group of crops per workgroup)
                                 // when front_impl = 1; 0 = the per-layer choice of round 3 (front.hip there)
+    bool stem_fuse_ = true;     // option "stem_fuse": f16, uint8 input -- the stem conv is computed inside block 1's depthwise kernel (stemdw.hip)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster
                                 // front kernels a third chain only adds contention: 100.1 k vs 97.2 k crops/s at batch 64,

@@ -141,6 +141,24 @@ bool head7_supported(int dtype, int K, int N, int HW);
 void launch_head7(const Head7Args& a, hipStream_t stream);
 std::string kernel_name_head7(int dtype, int n);
 
+// ---- stemdw.hip -------------------------------------------------------------------------
+// f16: stem conv + BN + Swish fused with block 1's depthwise 3x3 + BN + Swish (whenet.py:8, 23-26): the 112 x 112 x 32 stem
+// output only exists as LDS tiles.  Bitwise the two kernels' results; the tile is plan_dw()'s block-1 plan.
+struct StemDwArgs {
+    const uint8_t* in;     // [n,224,224,3]
+    void* out;             // [n,112,112,32] half: block 1's depthwise output
+    const float* w;        // stem [27][32]
+    const float* bias;     // stem [32]
+    const float* lut;      // [3][256]
+    const float* wd;       // depthwise [9][32]
+    const float* bd;       // depthwise bias [32]
+    float* partial;        // [n][56 tiles][32] channel sums for se.hip
+    int n;
+};
+bool stemdw_supported(int dtype, const DwPlan& p, int k, int s, int H, int C);
+void launch_stemdw(const StemDwArgs& a, hipStream_t stream);
+const char* kernel_name_stemdw();
+
 // ---- front.hip --------------------------------------------------------------------------
 // expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).
 struct FrontPlan {

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void whenet_stem_mfma_kernel(const uint8_t* __
         for (int qq = 0; qq < 4; ++qq) {
             half4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = half_t(swish_f<false>(acc[4 * qq + r] + bv[qq][r]));
+            for (int r = 0; r < 4; ++r) o[r] = f32_then_f16(swish_f<false>(acc[4 * qq + r] + bv[qq][r]));
             *reinterpret_cast<half4*>(so + lm * OPITCH + 8 * qq + 4 * g) = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's own LDS region: no barrier needed)

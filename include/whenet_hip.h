@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-/* (round 4 also: options front7, head_fuse.)
+/* (round 4 also: options front7, head_fuse, stem_fuse.)
  * 2 (round 3): whenet_op_trunk / whenet_op_stem_dw removed with their kernels; whenet_create_postproc and
  * whenet_op_block_range added; options front_impl, se_fuse, fold12, poison.
  * 3 (round 4): whenet_launch_stat_t carries the crops and chains of the launch it describes (what whenet_profile
@@ -118,6 +118,9 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "head_fuse" (0/1, default 1: the head conv (whenet.py:8, last layer) pools its own output, the
  *                  GlobalAveragePooling2D of whenet.py:10, in one kernel (head7.hip; f16, and f32 since round 4b); 0 = conv, then pooling
  *                  inside the heads kernel),
+ *          "stem_fuse" (0/1, default 1: f16 handles fed uint8 crops compute the stem conv (whenet.py:8, first layer) inside block 1's
+ *                  depthwise kernel (stemdw.hip): the 112 x 112 x 32 stem output never reaches HBM, one launch less; results are
+ *                  BITWISE those of the two kernels; 0 = stem.hip, then dw.hip.  The float32-input entry points keep the two),
  *          "fold12" (0/1, default 1: f16 handles whose block 2 runs front2.hip feed that kernel from block 1's depthwise
  *                  output, with block 1's project conv (linear) composed into block 2's expand weights when the
  *                  snapshot is loaded -- one launch and a 112x112x16 round trip through HBM less; 0 = the two convs

@@ -86,14 +86,16 @@ def test_info(handle):
     # rule on front.hip's tile plans); 36 with se_fuse=2 (every block with a fused front kernel)
     # f16 handles drop block 1's project launch (option fold12: folded into block 2's expand weights)
     assert i.macs_per_crop == spec.TOTAL_MACS and 35 <= i.n_kernels_per_forward <= 50
+    # ... and the stem launch (option stem_fuse: computed inside block 1's depthwise kernel, stemdw.hip)
     folded = 1 if handle.name == "f16" else 0
+    stemdw = 1 if handle.name == "f16" else 0
     try:
         handle.set_option("se_fuse", 0)
-        assert handle.info().n_kernels_per_forward == 51 - folded
+        assert handle.info().n_kernels_per_forward == 51 - folded - stemdw
         handle.set_option("se_fuse", 2)
-        assert handle.info().n_kernels_per_forward == 36 - folded
+        assert handle.info().n_kernels_per_forward == 36 - folded - stemdw
         handle.set_option("fold12", 0)
-        assert handle.info().n_kernels_per_forward == 36
+        assert handle.info().n_kernels_per_forward == 36 - stemdw
     finally:
         handle.set_option("fold12", 1)
         handle.set_option("se_fuse", 1)
@@ -320,6 +322,45 @@ def test_head_conv_fused_with_pooling_f32(blob, taps, golden):
         h.set_option("head_fuse", 0)
         y0, a0, l0 = h.forward(crops)
         assert np.abs(l0 - l21).max() < 1e-3 and np.abs(y0 - y21).max() < 1e-3
+
+
+def test_stem_fused_with_block_1_depthwise_is_bitwise_the_two_kernels(blob, golden):
+    """Round 4 (stemdw.hip; whenet.py:8, 23-26): for f16 handles fed uint8 crops the stem conv is computed inside block 1's
+    depthwise kernel -- the 112 x 112 x 32 stem output never reaches HBM.  The arithmetic is the two kernels' instruction for
+    instruction: logits, angles and bins must be BITWISE those of option stem_fuse=0, for every batch split, with and
+    without fold12; one launch less; the float32-input entry point (no byte LUT) keeps the two kernels."""
+    crops = np.concatenate([golden["crops"], synth.scene_crops(13, seed=31)])          # 21 crops
+    with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
+        k1 = h.info().n_kernels_per_forward
+        y1, a1, l1 = h.forward(crops)
+        h.set_option("stem_fuse", 0)
+        assert h.info().n_kernels_per_forward == k1 + 1
+        y0, a0, l0 = h.forward(crops)
+        assert np.array_equal(l1, l0) and np.array_equal(y1, y0) and np.array_equal(a1, a0)
+        h.set_option("stem_fuse", 1)
+        for lo, hi in ((0, 1), (1, 3), (0, 16), (4, 21), (20, 21)):
+            y, a, l = h.forward(crops[lo:hi])
+            assert np.array_equal(l, l1[lo:hi]) and np.array_equal(y, y1[lo:hi]), (lo, hi)
+        h.set_option("fold12", 0)
+        try:
+            yf1, af1, lf1 = h.forward(crops)
+            h.set_option("stem_fuse", 0)
+            yf0, af0, lf0 = h.forward(crops)
+            assert np.array_equal(lf1, lf0) and np.array_equal(yf1, yf0)
+        finally:
+            h.set_option("fold12", 1)
+            h.set_option("stem_fuse", 1)
+        d = h.device_alloc(crops[:8].nbytes)
+        try:
+            h.h2d(d, crops[:8])
+            names = [s["kernel"] for s in h.profile(d, 8, 2)]
+        finally:
+            h.device_free(d)
+        assert "whenet_stemdw_kernel" in names and not any("whenet_dw_kernel" in k or "whenet_stem_mfma" in k for k in names)
+    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
+        k = h.info().n_kernels_per_forward
+        h.set_option("stem_fuse", 0)
+        assert h.info().n_kernels_per_forward == k           # f32 handles: never fused
 
 
 def test_decode_kernel(handle):

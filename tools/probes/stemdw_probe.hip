@@ -1,0 +1,107 @@
+// Probe for stemdw.hip: the fused stem + block-1 depthwise kernel against stem.hip followed by dw.hip on random bytes --
+// bitwise comparison of the depthwise output and the per-tile channel sums (first mismatches are printed), and timing
+// at 256 / 64 / 16 / 1 crops.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/probes/stemdw_probe.hip -o tools/probes/stemdw_probe
+#define WHENET_STEMDW_DEBUG 1
+#include "../../headposeestimation-whenet_amd/csrc/stem.hip"
+#include "../../headposeestimation-whenet_amd/csrc/dw.hip"
+#include "../../headposeestimation-whenet_amd/csrc/stemdw.hip"
+
+#include <cstring>
+#include <vector>
+
+using namespace whenet;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+static float frand(float s) { return s * (float(rand() % 2001) / 1000.f - 1.f); }
+template <typename T> T* upload(const std::vector<T>& h) {
+    T* d; CK(hipMalloc(&d, std::max<size_t>(h.size(), 1) * sizeof(T)));
+    CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+int main() {
+    const int NMAX = 256;
+    srand(11);
+    std::vector<uint8_t> img(size_t(NMAX) * 224 * 224 * 3);
+    for (auto& v : img) v = uint8_t(rand() & 255);
+    std::vector<float> w(27 * 32), b(32), lut(768), wd(9 * 32), bd(32);
+    for (auto& v : w) v = frand(0.3f);
+    for (auto& v : b) v = frand(0.2f);
+    for (auto& v : wd) v = frand(0.4f);
+    for (auto& v : bd) v = frand(0.2f);
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c) for (int i = 0; i < 256; ++i) lut[c * 256 + i] = (float(i) / 255.f - mean[c]) / sd[c];
+    const uint8_t* d_img = upload(img);
+    const float *d_w = upload(w), *d_b = upload(b), *d_lut = upload(lut), *d_wd = upload(wd), *d_bd = upload(bd);
+    const size_t act = size_t(NMAX) * 112 * 112 * 32;
+    half_t *d_stem, *d_dw0, *d_dw1; float *d_p0, *d_p1;
+    CK(hipMalloc(&d_stem, act * 2)); CK(hipMalloc(&d_dw0, act * 2)); CK(hipMalloc(&d_dw1, act * 2));
+    CK(hipMalloc(&d_p0, size_t(NMAX) * 56 * 32 * 4)); CK(hipMalloc(&d_p1, size_t(NMAX) * 56 * 32 * 4));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const DwPlan plan = plan_dw(WHENET_F16, 3, 1, 112, 112, 32);
+    printf("plan: threads %d CV %d TH %d NSX %d tiles %d x %d chunks %d -> stemdw_supported %d\n", plan.threads, plan.CV, plan.TH, plan.NSX,
+           plan.tiles_x, plan.tiles_y, plan.chunks, int(stemdw_supported(WHENET_F16, plan, 3, 1, 112, 32)));
+    auto two = [&](int n) {
+        StemArgs a{d_img, d_stem, d_w, d_b, d_lut, n};
+        launch_stem(a, WHENET_F16, st);
+        DwArgs d{};
+        d.in = d_stem; d.out = d_dw0; d.w = d_wd; d.bias = d_bd; d.partial = d_p0; d.k = 3; d.s = 1; d.H = 112; d.Ho = 112; d.C = 32; d.pad = 1;
+        d.n = n; d.plan = plan;
+        launch_dw(d, WHENET_F16, st);
+    };
+    auto one = [&](int n) {
+        StemDwArgs a{d_img, d_dw1, d_w, d_b, d_lut, d_wd, d_bd, d_p1, n};
+        launch_stemdw(a, st);
+    };
+    const int NCHK = 3;
+    CK(hipMemset(d_dw1, 0xff, act * 2));
+    half_t* d_sdbg; CK(hipMalloc(&d_sdbg, size_t(NCHK) * 112 * 112 * 32 * 2));
+    CK(hipMemset(d_sdbg, 0xff, size_t(NCHK) * 112 * 112 * 32 * 2));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stemdw_dbg), &d_sdbg, sizeof(d_sdbg)));
+    two(NCHK); one(NCHK);
+    CK(hipStreamSynchronize(st));
+    {
+        half_t* nul = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stemdw_dbg), &nul, sizeof(nul)));
+        std::vector<uint16_t> s0(size_t(NCHK) * 112 * 112 * 32), s1(s0.size());
+        CK(hipMemcpy(s0.data(), d_stem, s0.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(s1.data(), d_sdbg, s1.size() * 2, hipMemcpyDeviceToHost));
+        size_t sb = 0;
+        for (size_t i = 0; i < s0.size(); ++i)
+            if (s0[i] != s1[i]) {
+                if (sb < 12) printf("  stem mismatch crop %d y %3d x %3d c %2d: stem.hip %04x fused %04x\n", int(i / 32 / 112 / 112), int((i / 32 / 112) % 112),
+                                    int((i / 32) % 112), int(i % 32), s0[i], s1[i]);
+                ++sb;
+            }
+        printf("stem values: %zu of %zu differ\n", sb, s0.size());
+    }
+    std::vector<uint16_t> h0(size_t(NCHK) * 112 * 112 * 32), h1(h0.size());
+    CK(hipMemcpy(h0.data(), d_dw0, h0.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h1.data(), d_dw1, h1.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < h0.size(); ++i)
+        if (h0[i] != h1[i]) {
+            if (bad < 12) {
+                const int c = int(i % 32), x = int((i / 32) % 112), y = int((i / 32 / 112) % 112), n = int(i / 32 / 112 / 112);
+                printf("  mismatch crop %d y %3d x %3d c %2d: two %04x one %04x\n", n, y, x, c, h0[i], h1[i]);
+            }
+            ++bad;
+        }
+    std::vector<float> p0(size_t(NCHK) * 56 * 32), p1(p0.size());
+    CK(hipMemcpy(p0.data(), d_p0, p0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(p1.data(), d_p1, p1.size() * 4, hipMemcpyDeviceToHost));
+    printf("depthwise output: %zu of %zu values differ; channel sums %s\n", bad, h0.size(),
+           std::memcmp(p0.data(), p1.data(), p0.size() * 4) == 0 ? "bitwise equal" : "DIFFER");
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](auto&& fn, int n) {
+        for (int i = 0; i < 3; ++i) fn(n);
+        CK(hipEventRecord(e0, st));
+        const int it = n >= 64 ? 20 : 50;
+        for (int i = 0; i < it; ++i) fn(n);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1000.f / it;
+    };
+    for (int n : {256, 64, 32, 16, 1}) printf("n=%3d: stem + dw %8.2f us   stemdw %8.2f us\n", n, timeit(two, n), timeit(one, n));
+    return 0;
+}
