@@ -39,11 +39,13 @@ __device__ __forceinline__ float conv_swish(float x) {
 // f32 -> f16 of a value the kernel has just computed, as TWO roundings (the f32 result, then binary16), whatever the optimiser
 // would like to fuse.  Left alone it turns half(x * r) into v_fma_mix (one rounding) in some kernels and into v_mul + v_cvt
 // in others, depending on the code around it: 1 value in 20 000 then differs by an ulp.  Kernels whose results must agree
-// bitwise (stem.hip + dw.hip against stemdw.hip) convert through this.
-__device__ __forceinline__ half_t f32_then_f16(float y) {
+// bitwise (stem.hip + dw.hip against stemdw.hip) convert through this; the same goes for `sum += x * r`, which the optimiser
+// contracts into an FMA in one kernel and not in the other (opaque_f32() on the product).
+__device__ __forceinline__ float opaque_f32(float y) {      // the value as a rounded f32 in a register: nothing fuses across this
     asm volatile("" : "+v"(y));
-    return half_t(y);
+    return y;
 }
+__device__ __forceinline__ half_t f32_then_f16(float y) { return half_t(opaque_f32(y)); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
 // loads and stores (s_waitcnt vmcnt(0)), which would stall prefetched operands and output stores

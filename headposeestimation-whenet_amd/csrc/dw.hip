@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void whenet_dw_kernel(const T* __restrict__ in
             VCT o;
 #pragma unroll
             for (int v = 0; v < VC; ++v) {
-                const float y = conv_swish<T>(acc[p][v] + bs[v]);
+                const float y = opaque_f32(conv_swish<T>(acc[p][v] + bs[v]));     // (pinned: stemdw.hip must reproduce these bits)
                 sum[v] += y;
                 o[v] = T(y);
             }

@@ -51,6 +51,11 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : 
     d_lut_ = static_cast<float*>(upload_bytes(&m.lut[0][0], sizeof(m.lut)));
     d_stem_w_ = upload(m.stem_w);
     d_stem_b_ = upload(m.stem_b);
+    {
+        StemDwTable t;
+        build_stemdw_table(m.stem_w.data(), &m.lut[0][0], &t);
+        d_stemdw_tab_ = static_cast<StemDwTable*>(upload_bytes(&t, sizeof(t)));
+    }
     for (const HostBlock& hb : m.blocks) {
         DevBlock b;
         b.spec = hb.spec;
@@ -627,9 +632,8 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         StemDwArgs a{};
         a.in = d_in;
         a.out = fold ? v.x1 : v.d;
-        a.w = d_stem_w_;
+        a.tab = d_stemdw_tab_;
         a.bias = d_stem_b_;
-        a.lut = d_lut_;
         a.wd = b1.dw.w;
         a.bd = b1.dw.bias;
         a.partial = v.partial;

@@ -199,6 +199,7 @@ class Engine {
     // weights
     std::vector<void*> weight_allocs_;
     float *d_lut_ = nullptr, *d_stem_w_ = nullptr, *d_stem_b_ = nullptr;
+    StemDwTable* d_stemdw_tab_ = nullptr;   // stemdw.hip's packed LUT + stem weight fragments
     std::vector<DevBlock> blocks_;
     DevPw head_;
     DevPw fold12_pw_;           // block 1 project x block 2 expand, 32 -> 96 (snapshot.cpp)

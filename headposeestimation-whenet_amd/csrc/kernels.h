@@ -144,12 +144,19 @@ std::string kernel_name_head7(int dtype, int n);
 // ---- stemdw.hip -------------------------------------------------------------------------
 // f16: stem conv + BN + Swish fused with block 1's depthwise 3x3 + BN + Swish (whenet.py:8, 23-26): the 112 x 112 x 32 stem
 // output only exists as LDS tiles.  Bitwise the two kernels' results; the tile is plan_dw()'s block-1 plan.
+// what every workgroup would otherwise rebuild from the f32 tensors: built once per model on the host (build_stemdw_table),
+// with the roundings stem.hip applies on the device
+struct StemDwTable {
+    uint32_t lut[3 * 256];          // the normalisation LUT as binary16 hi | lo << 16 (v = hi + lo)
+    half8 whi[3][64], wlo[3][64];   // stem weights split the same way, as MFMA fragments per kernel row and lane
+};
+void build_stemdw_table(const float* w /* [27][32] */, const float* lut /* [3][256] */, StemDwTable* out);
+
 struct StemDwArgs {
     const uint8_t* in;     // [n,224,224,3]
     void* out;             // [n,112,112,32] half: block 1's depthwise output
-    const float* w;        // stem [27][32]
+    const StemDwTable* tab;// (device)
     const float* bias;     // stem [32]
-    const float* lut;      // [3][256]
     const float* wd;       // depthwise [9][32]
     const float* bd;       // depthwise bias [32]
     float* partial;        // [n][56 tiles][32] channel sums for se.hip

@@ -9,8 +9,9 @@
 // A workgroup owns dw.hip's tile of block 1 -- 16 x 14 output pixels x 32 channels of one crop, i.e. plan_dw()'s (CV 4, TH 16,
 // NSX 2) plan, so the per-tile channel sums land where se.hip expects them -- and computes the 18 x 16 stem pixels under it
 // (halo 1: 1.29 x the stem arithmetic, which is 81 MFMAs per workgroup) from a 37 x 33 pixel patch of the crop:
-//   1. the patch's bytes (26 aligned dwords per row) and the LUT are requested together; the LUT is packed as in stem.hip
-//      (binary16 hi | lo << 16), the patch goes through it into LDS;
+//   1. the patch's bytes (26 aligned dwords per row), the LUT and the stem weight fragments -- both already split into binary16
+//      hi | lo as stem.hip splits them, once per model on the host (StemDwTable) -- are requested together; the patch goes
+//      through the LUT into LDS, 16 bytes (4 values) per store;
 //   2. 9 strips of 32 stem pixels over the 4 waves, stem.hip's arithmetic instruction for instruction (k-step = kernel row,
 //      hi/lo split products accumulated in f32, BN bias + Swish, one rounding to f16) -> the depthwise input tile in LDS
 //      [288 pixels][32 channels]; stem pixels outside the 112 x 112 map are the depthwise conv's 'SAME' zeros;
@@ -19,6 +20,7 @@
 // HBM bytes per crop: 150,528 in (1.36 x through L2) + 802,816 out.
 #include "device_math.h"
 #include "kernels.h"
+#include "stamps.h"
 
 namespace whenet {
 
@@ -28,8 +30,8 @@ constexpr int SD_TH = 16, SD_NSX = 2, SD_TILES_X = 8, SD_TILES_Y = 7;       // p
 constexpr int SD_IH = SD_TH + 2, SD_IW = SD_NSX * 7 + 2;                    // 18 x 16 stem pixels per tile
 constexpr int SD_NPIX = SD_IH * SD_IW, SD_NSTRIP = SD_NPIX / 32;            // 288, 9
 constexpr int SD_PR = 2 * SD_IH + 1, SD_PC = 2 * SD_IW + 1;                 // 37 x 33 input pixels per tile
-constexpr int SD_ROWW = 100;                                                // dwords per staged patch row (99 values + 1)
 constexpr int SD_RDW = 26;                                                  // aligned dwords per patch row (2 + 99 + 3 bytes)
+constexpr int SD_ROWW = 4 * SD_RDW;                                         // staged row: the 104 bytes' values, value v at index v + 2
 constexpr int SD_C = 32, SD_CG = SD_C / 4, SD_P = 7;
 static_assert(SD_NPIX % 32 == 0 && SD_TH * SD_NSX * SD_CG == 256, "tile / lane geometry");
 
@@ -38,11 +40,11 @@ __device__ half_t* g_stemdw_dbg = nullptr;
 #endif
 
 __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __restrict__ in, half_t* __restrict__ out,
-                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                            const float* __restrict__ lut, const float* __restrict__ wd,
-                                                            const float* __restrict__ bd, float* __restrict__ partial) {
+                                                            const StemDwTable* __restrict__ tab, const float* __restrict__ bias,
+                                                            const float* __restrict__ wd, const float* __restrict__ bd,
+                                                            float* __restrict__ partial) {
     __shared__ uint32_t s_lut[3 * 256];                                      // packed binary16 (hi | lo << 16), as stem.hip
-    __shared__ __attribute__((aligned(16))) uint32_t s_img[SD_PR * SD_ROWW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_img[SD_PR * SD_ROWW + 8];    // (+8: the last row's fragment reads run past it)
     __shared__ __attribute__((aligned(16))) half_t s_tile[SD_NPIX * SD_C];   // the depthwise input tile; aliased by s_red
     __shared__ __attribute__((aligned(16))) float s_w[9 * SD_C];
     float* s_red = reinterpret_cast<float*>(s_tile);                         // [32 strips][32 channels]
@@ -55,69 +57,64 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
     const int b = blockIdx.y;
     const int oy0 = tyi * SD_TH, ox0 = txi * SD_NSX * SD_P;
     const int sy0 = oy0 - 1, sx0 = ox0 - 1;                                  // stem pixel of the tile's corner (may be -1)
+    STAMP(0);
 
-    // ---- stem weights / biases, depthwise weights, the patch, the LUT: one global round trip ------------------------------
-    float wv[3][8];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = 8 * g + e;
-            wv[ky][e] = (j < 9) ? w[(ky * 9 + j) * STEM_C + lm] : 0.0f;
-        }
-    float4v bv[4];
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) bv[qq] = *reinterpret_cast<const float4v*>(bias + 8 * qq + 4 * g);
+    // ---- the patch, the LUT, the stem weight fragments, the depthwise weights: one global round trip ------------------------
     // patch row r = input row 2 * sy0 + r; its 99 values start at byte 6 * sx0 of the row (== 2 mod 4): dword j of the row
-    // covers values 4j - 2 .. 4j + 1
+    // covers values 4j - 2 .. 4j + 1.  Image rows are 168 dwords: a dword is inside the row or outside it, never across.
     constexpr int NLD = (SD_PR * SD_RDW + 255) / 256;                        // 4
     const uint8_t* img = in + size_t(b) * IMG * IMG * 3;
     const int byte0 = 6 * sx0 - 2;                                           // (multiple of 4; -8 for the leftmost tiles)
     uint32_t raw[NLD];
+    bool rok[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int d = tid + 256 * i;
         const int r = d / SD_RDW, j = d - r * SD_RDW;
         const int iy = 2 * sy0 + r;
         const int bo = byte0 + 4 * j;
-        const bool ok = d < SD_PR * SD_RDW && iy >= 0 && iy < IMG && bo >= 0 && bo < IMG * 3;
-        raw[i] = ok ? *reinterpret_cast<const uint32_t*>(img + size_t(iy) * (IMG * 3) + bo) : 0u;
+        rok[i] = d < SD_PR * SD_RDW && iy >= 0 && iy < IMG && bo >= 0 && bo < IMG * 3;     // (else: padding, zero)
+        raw[i] = rok[i] ? *reinterpret_cast<const uint32_t*>(img + size_t(iy) * (IMG * 3) + bo) : 0u;
     }
-    auto pack = [](float v) -> uint32_t {
-        const half_t hi = half_t(v), lo = half_t(v - float(hi));
-        return uint32_t(__builtin_bit_cast(unsigned short, hi)) | (uint32_t(__builtin_bit_cast(unsigned short, lo)) << 16);
-    };
-    for (int i = tid; i < 3 * 256; i += 256) s_lut[i] = pack(lut[i]);
-    for (int i = tid; i < 9 * SD_C; i += 256) s_w[i] = wd[i];
+    uint32_t lutv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lutv[i] = tab->lut[tid + 256 * i];
+    half8 whi[3], wlo[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        whi[ky] = tab->whi[ky][lane];
+        wlo[ky] = tab->wlo[ky][lane];
+    }
+    float4v bv[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) bv[qq] = *reinterpret_cast<const float4v*>(bias + 8 * qq + 4 * g);
+    const float wdv0 = wd[tid], wdv1 = (tid < 9 * SD_C - 256) ? wd[256 + tid] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s_lut[tid + 256 * i] = lutv[i];
+    s_w[tid] = wdv0;
+    if (tid < 9 * SD_C - 256) s_w[256 + tid] = wdv1;
+    if (tid < 8) s_img[SD_PR * SD_ROWW + tid] = 0u;
     __syncthreads();
+    STAMP(1);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int d = tid + 256 * i;
         if (d >= SD_PR * SD_RDW) continue;
-        const int r = d / SD_RDW, j = d - r * SD_RDW;
-        const int iy = 2 * sy0 + r;
-        const int bo = byte0 + 4 * j;
-        const bool row_ok = iy >= 0 && iy < IMG;                              // (row 224: the stem's bottom padding, zero)
+        const int j = d % SD_RDW;
         int ch = (j + 1) % 3;                                                 // channel of value 4j - 2 (values start at a pixel)
+        uint4 val;
+        uint32_t* vp = reinterpret_cast<uint32_t*>(&val);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int v = 4 * j - 2 + q;                                     // value index in the patch row
-            const int bq = bo + q;                                            // byte in the image row; 672.. = right padding
-            // (bytes outside the row were not loaded: raw = 0 there, the lookup is harmless and the result discarded)
-            const uint32_t val = (row_ok && bq >= 0 && bq < IMG * 3) ? s_lut[ch * 256 + ((raw[i] >> (8 * q)) & 0xff)] : 0u;
-            if (v >= 0 && v < SD_PC * 3) s_img[r * SD_ROWW + v] = val;
+            // (dwords outside the image were not loaded: raw = 0, the lookup is harmless and the result discarded)
+            const uint32_t t = s_lut[ch * 256 + ((raw[i] >> (8 * q)) & 0xff)];
+            vp[q] = rok[i] ? t : 0u;
             ch = (ch == 2) ? 0 : ch + 1;
         }
+        *reinterpret_cast<uint4*>(&s_img[4 * d]) = val;                       // row r, values 4j - 2 .. 4j + 1 at index 4j .. 4j + 3
     }
-    half8 whi[3], wlo[3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            whi[ky][e] = half_t(wv[ky][e]);
-            wlo[ky][e] = half_t(wv[ky][e] - float(whi[ky][e]));
-        }
     __syncthreads();
+    STAMP(2);
 
     // ---- the stem conv of the tile's 288 pixels -> s_tile (stem.hip's strip loop) -------------------------------------------
     for (int strip = wave; strip < SD_NSTRIP; strip += 4) {
@@ -128,19 +125,15 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const uint32_t* row = &s_img[(2 * pr + ky) * SD_ROWW + pc * 6 + 8 * g];
+            // 8 packed values of this lane's k-group.  g = 1 holds the ninth value of the kernel row and seven that belong to
+            // the next pixels: their weights are zero (the fragment table), the values finite -- stem.hip zeroes them instead
+            const uint32_t* row = &s_img[(2 * pr + ky) * SD_ROWW + 2 + pc * 6 + 8 * g];
             uint32_t d[8];
-            if (g == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(row + 2 * i);
-                    d[2 * i] = v.x;
-                    d[2 * i + 1] = v.y;
-                }
-            } else {
-                d[0] = row[0];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) d[i] = 0u;
+            for (int i = 0; i < 4; ++i) {
+                const uint2 v = *reinterpret_cast<const uint2*>(row + 2 * i);
+                d[2 * i] = v.x;
+                d[2 * i + 1] = v.y;
             }
             uint32_t ph[4], pl[4];
 #pragma unroll
@@ -171,6 +164,7 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
         }
     }
     __syncthreads();
+    STAMP(3);
 
     // ---- depthwise 3x3 on the tile (dw.hip's compute: lane = 4-channel group cg x strip sidx) -------------------------------
     using VCT = half_t __attribute__((ext_vector_type(4)));
@@ -209,6 +203,7 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
             }
         }
     }
+    STAMP(4);
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
     {
         const float4v bs = *reinterpret_cast<const float4v*>(bd + cg * 4);
@@ -218,13 +213,14 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
             VCT o;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float y = conv_swish<half_t>(acc[p][v] + bs[v]);
+                const float y = opaque_f32(conv_swish<half_t>(acc[p][v] + bs[v]));
                 sum[v] += y;
-                o[v] = f32_then_f16(y);
+                o[v] = half_t(y);
             }
             *reinterpret_cast<VCT*>(dst + size_t(p) * SD_C) = o;
         }
     }
+    STAMP(5);
     lds_barrier();                               // everyone is done reading s_tile
 #pragma unroll
     for (int v = 0; v < 4; ++v) s_red[sidx * SD_C + cg * 4 + v] = sum[v];
@@ -234,6 +230,7 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
         for (int s = 0; s < SD_TH * SD_NSX; ++s) t += s_red[s * SD_C + tid];
         partial[(size_t(b) * (SD_TILES_X * SD_TILES_Y) + tile) * SD_C + tid] = t;
     }
+    STAMP(6);
 }
 
 }  // namespace
@@ -244,11 +241,28 @@ bool stemdw_supported(int dtype, const DwPlan& p, int k, int s, int H, int C) {
            p.NSX == SD_NSX && p.tiles_x == SD_TILES_X && p.tiles_y == SD_TILES_Y && p.chunks == 1;
 }
 
+void build_stemdw_table(const float* w, const float* lut, StemDwTable* out) {
+    // (host: _Float16 conversions round to nearest even, as v_cvt_f16_f32 does; the subtraction is exact in f32)
+    for (int i = 0; i < 3 * 256; ++i) {
+        const half_t hi = half_t(lut[i]), lo = half_t(lut[i] - float(hi));
+        out->lut[i] = uint32_t(__builtin_bit_cast(unsigned short, hi)) | (uint32_t(__builtin_bit_cast(unsigned short, lo)) << 16);
+    }
+    for (int ky = 0; ky < 3; ++ky)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const int j = 8 * (lane >> 5) + e;                            // (kx, ci) of the kernel row; 9.. are zero weights
+                const float v = (j < 9) ? w[(ky * 9 + j) * STEM_C + (lane & 31)] : 0.0f;
+                const half_t hi = half_t(v);
+                out->whi[ky][lane][e] = hi;
+                out->wlo[ky][lane][e] = half_t(v - float(hi));
+            }
+}
+
 void launch_stemdw(const StemDwArgs& a, hipStream_t stream) {
-    WHENET_REQUIRE(a.in && a.out && a.w && a.bias && a.lut && a.wd && a.bd && a.partial && a.n >= 1, WHENET_EINVAL,
+    WHENET_REQUIRE(a.in && a.out && a.tab && a.bias && a.wd && a.bd && a.partial && a.n >= 1, WHENET_EINVAL,
                    "stemdw: missing argument");
     hipLaunchKernelGGL(whenet_stemdw_kernel, dim3(SD_TILES_X * SD_TILES_Y, a.n), dim3(256), 0, stream, a.in,
-                       static_cast<half_t*>(a.out), a.w, a.bias, a.lut, a.wd, a.bd, a.partial);
+                       static_cast<half_t*>(a.out), a.tab, a.bias, a.wd, a.bd, a.partial);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 

@@ -1,12 +1,13 @@
 // Probe for stemdw.hip: the fused stem + block-1 depthwise kernel against stem.hip followed by dw.hip on random bytes --
 // bitwise comparison of the depthwise output and the per-tile channel sums (first mismatches are printed), and timing
 // at 256 / 64 / 16 / 1 crops.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/probes/stemdw_probe.hip -o tools/probes/stemdw_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWHENET_STAMPS] -Iinclude tools/probes/stemdw_probe.hip -o tools/probes/stemdw_probe
 #define WHENET_STEMDW_DEBUG 1
 #include "../../headposeestimation-whenet_amd/csrc/stem.hip"
 #include "../../headposeestimation-whenet_amd/csrc/dw.hip"
 #include "../../headposeestimation-whenet_amd/csrc/stemdw.hip"
 
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -23,7 +24,13 @@ int main() {
     const int NMAX = 256;
     srand(11);
     std::vector<uint8_t> img(size_t(NMAX) * 224 * 224 * 3);
-    for (auto& v : img) v = uint8_t(rand() & 255);
+    // smooth images by default (neighbouring bytes close: the LUT reads of a wave mostly share banks, as on photographs);
+    // NOISE=1: independent random bytes, the worst case for the LUT reads
+    const bool noise = getenv("NOISE") != nullptr;
+    for (size_t i = 0; i < img.size(); ++i) {
+        const int x = int((i / 3) % 224), y = int((i / 3 / 224) % 224), c = int(i % 3);
+        img[i] = noise ? uint8_t(rand() & 255) : uint8_t(128 + 100 * std::sin(0.05 * x + 0.03 * y + c) + (rand() % 7));
+    }
     std::vector<float> w(27 * 32), b(32), lut(768), wd(9 * 32), bd(32);
     for (auto& v : w) v = frand(0.3f);
     for (auto& v : b) v = frand(0.2f);
@@ -33,6 +40,8 @@ int main() {
     for (int c = 0; c < 3; ++c) for (int i = 0; i < 256; ++i) lut[c * 256 + i] = (float(i) / 255.f - mean[c]) / sd[c];
     const uint8_t* d_img = upload(img);
     const float *d_w = upload(w), *d_b = upload(b), *d_lut = upload(lut), *d_wd = upload(wd), *d_bd = upload(bd);
+    StemDwTable htab; build_stemdw_table(w.data(), lut.data(), &htab);
+    StemDwTable* d_tab; CK(hipMalloc(&d_tab, sizeof(htab))); CK(hipMemcpy(d_tab, &htab, sizeof(htab), hipMemcpyHostToDevice));
     const size_t act = size_t(NMAX) * 112 * 112 * 32;
     half_t *d_stem, *d_dw0, *d_dw1; float *d_p0, *d_p1;
     CK(hipMalloc(&d_stem, act * 2)); CK(hipMalloc(&d_dw0, act * 2)); CK(hipMalloc(&d_dw1, act * 2));
@@ -50,7 +59,7 @@ int main() {
         launch_dw(d, WHENET_F16, st);
     };
     auto one = [&](int n) {
-        StemDwArgs a{d_img, d_dw1, d_w, d_b, d_lut, d_wd, d_bd, d_p1, n};
+        StemDwArgs a{d_img, d_dw1, d_tab, d_b, d_wd, d_bd, d_p1, n};
         launch_stemdw(a, st);
     };
     const int NCHK = 3;
@@ -102,6 +111,31 @@ int main() {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         return ms * 1000.f / it;
     };
+#ifdef WHENET_STAMPS
+    for (int n : {256, 64, 16}) {
+        const size_t nwg = size_t(56) * n;
+        long long* d_st; CK(hipMalloc(&d_st, nwg * 8 * sizeof(long long)));
+        CK(hipMemset(d_st, 0, nwg * 8 * sizeof(long long)));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(whenet_stamps), &d_st, sizeof(d_st)));
+        one(n);
+        CK(hipStreamSynchronize(st));
+        long long* nul = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(whenet_stamps), &nul, sizeof(nul)));
+        std::vector<long long> hs(nwg * 8);
+        CK(hipMemcpy(hs.data(), d_st, hs.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        double ph[6] = {0, 0, 0, 0, 0, 0}, life = 0;
+        long long t0 = hs[0], t1 = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            for (int i = 0; i < 6; ++i) ph[i] += double(hs[w * 8 + i + 1] - hs[w * 8 + i]);
+            life += double(hs[w * 8 + 6] - hs[w * 8]);
+            t0 = std::min(t0, hs[w * 8]); t1 = std::max(t1, hs[w * 8 + 6]);
+        }
+        printf("n=%3d timeline: %zu workgroups, kernel span %.1f us; workgroup life %.2f us = loads + LUT %.2f | patch -> LDS %.2f | stem strips %.2f | "
+               "depthwise taps %.2f | swish + stores %.2f | channel sums %.2f\n", n, nwg, double(t1 - t0) * 0.01, life / nwg * 0.01, ph[0] / nwg * 0.01,
+               ph[1] / nwg * 0.01, ph[2] / nwg * 0.01, ph[3] / nwg * 0.01, ph[4] / nwg * 0.01, ph[5] / nwg * 0.01);
+        CK(hipFree(d_st));
+    }
+#endif
     for (int n : {256, 64, 32, 16, 1}) printf("n=%3d: stem + dw %8.2f us   stemdw %8.2f us\n", n, timeit(two, n), timeit(one, n));
     return 0;
 }
