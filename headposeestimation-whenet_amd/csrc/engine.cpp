@@ -393,10 +393,10 @@ bool Engine::fold12_active() const {
            (front_impl_ == 2 || (front_impl_ == 1 && blocks_[1].f2_preferred));
 }
 
-// The stem's output is read by block 1's depthwise conv only (block 1 has no expand conv and no skip): for f16 handles fed
+// The stem's output is read by block 1's depthwise conv only (block 1 has no expand conv and no skip): for handles fed
 // uint8 crops the two are one kernel (stemdw.hip) when block 1's depthwise tile plan is the one that kernel is built for.
 bool Engine::stem_fuse_active() const {
-    if (!(stem_fuse_ && dtype_ == WHENET_F16 && !blocks_.empty())) return false;
+    if (!(stem_fuse_ && !blocks_.empty())) return false;
     const DevBlock& b = blocks_[0];
     return !b.spec.has_expand() && !b.spec.has_skip() &&
            stemdw_supported(dtype_, b.dw.plan, b.spec.k, b.spec.s, b.spec.h_in, b.spec.cexp());
@@ -630,6 +630,9 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         const DevBlock& b1 = blocks_[0];
         const bool fold = fold12_active() && blocks_.size() >= 2;
         StemDwArgs a{};
+        a.dtype = dtype_;
+        a.w = d_stem_w_;
+        a.lut = d_lut_;
         a.in = d_in;
         a.out = fold ? v.x1 : v.d;
         a.tab = d_stemdw_tab_;
@@ -638,7 +641,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.bd = b1.dw.bias;
         a.partial = v.partial;
         a.n = n;
-        R("stem+b1/dw", "stem", kernel_name_stemdw(), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * (10838016.0 + 112.0 * 112 * 9 * 32),
+        R("stem+b1/dw", "stem", kernel_name_stemdw(dtype_), double(n) * (IN_BYTES + X_ELEMS * es), 2.0 * n * (10838016.0 + 112.0 * 112 * 9 * 32),
           [&] { launch_stemdw(a, s); });
     } else {
         StemArgs a{d_in, v.x0, d_stem_w_, d_stem_b_, d_lut_, n};

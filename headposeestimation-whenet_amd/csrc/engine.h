@@ -181,7 +181,7 @@ class Engine {
     bool head_fuse_ = true;     // option "head_fuse": the head conv pools its own output (head7.hip, f16 and f32); 0 = round 3's two stages
     bool front7_ = true;        // option "front7": blocks 13-16 of an f16 handle run front7.hip (a group of crops per workgroup)
                                 // when front_impl = 1; 0 = the per-layer choice of round 3 (front.hip there)
-    bool stem_fuse_ = true;     // option "stem_fuse": f16, uint8 input -- the stem conv is computed inside block 1's depthwise kernel (stemdw.hip)
+    bool stem_fuse_ = true;     // option "stem_fuse": uint8 input -- the stem conv is computed inside block 1's depthwise kernel (stemdw.hip)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster
                                 // front kernels a third chain only adds contention: 100.1 k vs 97.2 k crops/s at batch 64,

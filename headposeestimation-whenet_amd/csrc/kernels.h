@@ -142,7 +142,7 @@ void launch_head7(const Head7Args& a, hipStream_t stream);
 std::string kernel_name_head7(int dtype, int n);
 
 // ---- stemdw.hip -------------------------------------------------------------------------
-// f16: stem conv + BN + Swish fused with block 1's depthwise 3x3 + BN + Swish (whenet.py:8, 23-26): the 112 x 112 x 32 stem
+// stem conv + BN + Swish fused with block 1's depthwise 3x3 + BN + Swish (whenet.py:8, 23-26), f16 and f32: the 112 x 112 x 32 stem
 // output only exists as LDS tiles.  Bitwise the two kernels' results; the tile is plan_dw()'s block-1 plan.
 // what every workgroup would otherwise rebuild from the f32 tensors: built once per model on the host (build_stemdw_table),
 // with the roundings stem.hip applies on the device
@@ -153,9 +153,12 @@ struct StemDwTable {
 void build_stemdw_table(const float* w /* [27][32] */, const float* lut /* [3][256] */, StemDwTable* out);
 
 struct StemDwArgs {
+    int dtype;             // WHENET_F16 / WHENET_F32
     const uint8_t* in;     // [n,224,224,3]
-    void* out;             // [n,112,112,32] half: block 1's depthwise output
-    const StemDwTable* tab;// (device)
+    void* out;             // [n,112,112,32] T: block 1's depthwise output
+    const StemDwTable* tab;// (device) f16
+    const float* w;        // f32: stem [27][32]
+    const float* lut;      // f32: [3][256]
     const float* bias;     // stem [32]
     const float* wd;       // depthwise [9][32]
     const float* bd;       // depthwise bias [32]
@@ -164,7 +167,7 @@ struct StemDwArgs {
 };
 bool stemdw_supported(int dtype, const DwPlan& p, int k, int s, int H, int C);
 void launch_stemdw(const StemDwArgs& a, hipStream_t stream);
-const char* kernel_name_stemdw();
+const char* kernel_name_stemdw(int dtype);
 
 // ---- front.hip --------------------------------------------------------------------------
 // expand 1x1 (MFMA) + BN + Swish -> depthwise kxk + BN + Swish in one kernel (blocks 2..16).

@@ -1,4 +1,4 @@
-// Stem conv fused with block 1's depthwise conv (f16, round 4): uint8 crop -> normalise -> Conv2D(32, 3x3, s2) + BN + Swish
+// Stem conv fused with block 1's depthwise conv (round 4; f16, and f32 further down): uint8 crop -> normalise -> Conv2D(32, 3x3, s2) + BN + Swish
 // -> DepthwiseConv2D(3x3, s1) + BN + Swish, plus the per-tile channel sums of block 1's squeeze-excite.
 //
 // Reference: /root/reference/whenet.py:23-26 (normalise) feeding efficientnet 0.0.4's stem and the first MBConv block's
@@ -233,12 +233,174 @@ __global__ __launch_bounds__(256) void whenet_stemdw_kernel(const uint8_t* __res
     STAMP(6);
 }
 
+// ---- f32 (the parity configuration) ---------------------------------------------------------------------------------------
+// The same kernel with stem.hip's f32 matrix-core stem (v_mfma_f32_32x32x2_f32: 15 per strip, an fmaf chain in k order) and
+// dw.hip's f32 instantiation; the tile is f32 (36 KB: the LUT, dead once the patch is staged, lives in its first 3 KB, which keeps
+// the workgroup at 52 KB -- three per CU).  As two kernels the stem output costs 103 MB written + 133 MB read per 64 crops.
+__global__ __launch_bounds__(256) void whenet_stemdw_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                                const float* __restrict__ lut, const float* __restrict__ wd,
+                                                                const float* __restrict__ bd, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float s_img[SD_PR * SD_ROWW + 8];
+    __shared__ __attribute__((aligned(16))) float s_tile[SD_NPIX * SD_C];     // aliased by s_lut (before) and s_red (after)
+    __shared__ __attribute__((aligned(16))) float s_w[9 * SD_C];
+    float* s_lut = s_tile;
+    float* s_red = s_tile;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, lm = lane & 31;
+    const int tile = blockIdx.x;
+    const int tyi = tile / SD_TILES_X, txi = tile - tyi * SD_TILES_X;
+    const int b = blockIdx.y;
+    const int oy0 = tyi * SD_TH, ox0 = txi * SD_NSX * SD_P;
+    const int sy0 = oy0 - 1, sx0 = ox0 - 1;
+
+    constexpr int NLD = (SD_PR * SD_RDW + 255) / 256;
+    const uint8_t* img = in + size_t(b) * IMG * IMG * 3;
+    const int byte0 = 6 * sx0 - 2;
+    uint32_t raw[NLD];
+    bool rok[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int d = tid + 256 * i;
+        const int r = d / SD_RDW, j = d - r * SD_RDW;
+        const int iy = 2 * sy0 + r;
+        const int bo = byte0 + 4 * j;
+        rok[i] = d < SD_PR * SD_RDW && iy >= 0 && iy < IMG && bo >= 0 && bo < IMG * 3;
+        raw[i] = rok[i] ? *reinterpret_cast<const uint32_t*>(img + size_t(iy) * (IMG * 3) + bo) : 0u;
+    }
+    float lutv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lutv[i] = lut[tid + 256 * i];
+    // weight operands: MFMA u of row ky contracts k = 2 u + g of the row's 9 values (k = 9: zero) -- as stem.hip
+    float wv[3][5];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int j = 2 * u + g;
+            wv[ky][u] = (j < 9) ? w[(ky * 9 + j) * STEM_C + lm] : 0.0f;
+        }
+    float4v bv[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) bv[qq] = *reinterpret_cast<const float4v*>(bias + 8 * qq + 4 * g);
+    const float wdv0 = wd[tid], wdv1 = (tid < 9 * SD_C - 256) ? wd[256 + tid] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s_lut[tid + 256 * i] = lutv[i];
+    s_w[tid] = wdv0;
+    if (tid < 9 * SD_C - 256) s_w[256 + tid] = wdv1;
+    if (tid < 8) s_img[SD_PR * SD_ROWW + tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int d = tid + 256 * i;
+        if (d >= SD_PR * SD_RDW) continue;
+        const int j = d % SD_RDW;
+        int ch = (j + 1) % 3;
+        float4v val;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = s_lut[ch * 256 + ((raw[i] >> (8 * q)) & 0xff)];
+            val[q] = rok[i] ? t : 0.f;
+            ch = (ch == 2) ? 0 : ch + 1;
+        }
+        *reinterpret_cast<float4v*>(&s_img[4 * d]) = val;
+    }
+    __syncthreads();                              // (also: the LUT is dead, the tile may be written)
+
+    for (int strip = wave; strip < SD_NSTRIP; strip += 4) {
+        const int p = strip * 32 + lm;
+        const int pr = p / SD_IW, pc = p - pr * SD_IW;
+        float16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = &s_img[(2 * pr + ky) * SD_ROWW + 2 + pc * 6 + g];
+#pragma unroll
+            for (int u = 0; u < 5; ++u)                        // (u = 4, g = 1 reads the next pixel's value against a zero weight)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ky][u], row[2 * u], acc, 0, 0, 0);
+        }
+        const int sy = sy0 + pr, sx = sx0 + pc;
+        const bool inside = sy >= 0 && sy < STEM_HW && sx >= 0 && sx < STEM_HW;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            float4v o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = opaque_f32(conv_swish<float>(acc[4 * qq + r] + bv[qq][r]));
+            if (!inside) o = float4v{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<float4v*>(s_tile + p * SD_C + 8 * qq + 4 * g) = o;
+        }
+    }
+    __syncthreads();
+
+    const int cg = tid % SD_CG;
+    const int sidx = tid / SD_CG;
+    const int ty = sidx / SD_NSX, sx = sidx - ty * SD_NSX;
+    const int oy = oy0 + ty;
+    float acc[SD_P][4];
+#pragma unroll
+    for (int p = 0; p < SD_P; ++p)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[p][v] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float wr[3][4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float4v t = *reinterpret_cast<const float4v*>(s_w + (ky * 3 + kx) * SD_C + cg * 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) wr[kx][v] = t[v];
+        }
+        const float* row = s_tile + size_t((ty + ky) * SD_IW + sx * SD_P) * SD_C + cg * 4;
+#pragma unroll
+        for (int ix = 0; ix < SD_P + 2; ++ix) {
+            const float4v xv = *reinterpret_cast<const float4v*>(row + ix * SD_C);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int d = ix - kx;
+                if (d >= 0 && d < SD_P) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[d][v] = fmaf(xv[v], wr[kx][v], acc[d][v]);
+                }
+            }
+        }
+    }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float4v bs = *reinterpret_cast<const float4v*>(bd + cg * 4);
+        float* dst = out + ((size_t(b) * STEM_HW + oy) * STEM_HW + (ox0 + sx * SD_P)) * SD_C + cg * 4;
+#pragma unroll
+        for (int p = 0; p < SD_P; ++p) {
+            float4v o;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float y = opaque_f32(conv_swish<float>(acc[p][v] + bs[v]));
+                sum[v] += y;
+                o[v] = y;
+            }
+            *reinterpret_cast<float4v*>(dst + size_t(p) * SD_C) = o;
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s_red[sidx * SD_C + cg * 4 + v] = sum[v];
+    lds_barrier();
+    if (tid < SD_C) {
+        float t = 0.0f;
+        for (int s = 0; s < SD_TH * SD_NSX; ++s) t += s_red[s * SD_C + tid];
+        partial[(size_t(b) * (SD_TILES_X * SD_TILES_Y) + tile) * SD_C + tid] = t;
+    }
+}
+
 }  // namespace
 
 // the fused kernel is dw.hip's block-1 tile: only that plan puts the channel sums where se.hip reads them
 bool stemdw_supported(int dtype, const DwPlan& p, int k, int s, int H, int C) {
-    return dtype == WHENET_F16 && k == 3 && s == 1 && H == STEM_HW && C == SD_C && p.threads == 256 && p.CV == 4 && p.TH == SD_TH &&
-           p.NSX == SD_NSX && p.tiles_x == SD_TILES_X && p.tiles_y == SD_TILES_Y && p.chunks == 1;
+    const int cv = dtype == WHENET_F16 ? 4 : 8;          // 16-byte vectors per pixel: all 32 channels in one chunk
+    return (dtype == WHENET_F16 || dtype == WHENET_F32) && k == 3 && s == 1 && H == STEM_HW && C == SD_C && p.threads == 256 &&
+           p.CV == cv && p.TH == SD_TH && p.NSX == SD_NSX && p.tiles_x == SD_TILES_X && p.tiles_y == SD_TILES_Y && p.chunks == 1;
 }
 
 void build_stemdw_table(const float* w, const float* lut, StemDwTable* out) {
@@ -259,13 +421,19 @@ void build_stemdw_table(const float* w, const float* lut, StemDwTable* out) {
 }
 
 void launch_stemdw(const StemDwArgs& a, hipStream_t stream) {
-    WHENET_REQUIRE(a.in && a.out && a.tab && a.bias && a.wd && a.bd && a.partial && a.n >= 1, WHENET_EINVAL,
-                   "stemdw: missing argument");
-    hipLaunchKernelGGL(whenet_stemdw_kernel, dim3(SD_TILES_X * SD_TILES_Y, a.n), dim3(256), 0, stream, a.in,
-                       static_cast<half_t*>(a.out), a.tab, a.bias, a.wd, a.bd, a.partial);
+    WHENET_REQUIRE(a.in && a.out && a.bias && a.wd && a.bd && a.partial && a.n >= 1, WHENET_EINVAL, "stemdw: missing argument");
+    if (a.dtype == WHENET_F16) {
+        WHENET_REQUIRE(a.tab != nullptr, WHENET_EINVAL, "stemdw: the f16 kernel takes the host-built table");
+        hipLaunchKernelGGL(whenet_stemdw_kernel, dim3(SD_TILES_X * SD_TILES_Y, a.n), dim3(256), 0, stream, a.in,
+                           static_cast<half_t*>(a.out), a.tab, a.bias, a.wd, a.bd, a.partial);
+    } else {
+        WHENET_REQUIRE(a.dtype == WHENET_F32 && a.w && a.lut, WHENET_EINVAL, "stemdw: the f32 kernel takes the f32 weights and LUT");
+        hipLaunchKernelGGL(whenet_stemdw_f32_kernel, dim3(SD_TILES_X * SD_TILES_Y, a.n), dim3(256), 0, stream, a.in,
+                           static_cast<float*>(a.out), a.w, a.bias, a.lut, a.wd, a.bd, a.partial);
+    }
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
-const char* kernel_name_stemdw() { return "whenet_stemdw_kernel"; }
+const char* kernel_name_stemdw(int dtype) { return dtype == WHENET_F16 ? "whenet_stemdw_kernel" : "whenet_stemdw_f32_kernel"; }
 
 }  // namespace whenet

@@ -88,7 +88,7 @@ def test_info(handle):
     assert i.macs_per_crop == spec.TOTAL_MACS and 35 <= i.n_kernels_per_forward <= 50
     # ... and the stem launch (option stem_fuse: computed inside block 1's depthwise kernel, stemdw.hip)
     folded = 1 if handle.name == "f16" else 0
-    stemdw = 1 if handle.name == "f16" else 0
+    stemdw = 1
     try:
         handle.set_option("se_fuse", 0)
         assert handle.info().n_kernels_per_forward == 51 - folded - stemdw
@@ -325,10 +325,11 @@ def test_head_conv_fused_with_pooling_f32(blob, taps, golden):
 
 
 def test_stem_fused_with_block_1_depthwise_is_bitwise_the_two_kernels(blob, golden):
-    """Round 4 (stemdw.hip; whenet.py:8, 23-26): for f16 handles fed uint8 crops the stem conv is computed inside block 1's
+    """Round 4 (stemdw.hip; whenet.py:8, 23-26): for handles fed uint8 crops the stem conv is computed inside block 1's
     depthwise kernel -- the 112 x 112 x 32 stem output never reaches HBM.  The arithmetic is the two kernels' instruction for
     instruction: logits, angles and bins must be BITWISE those of option stem_fuse=0, for every batch split, with and
-    without fold12; one launch less; the float32-input entry point (no byte LUT) keeps the two kernels."""
+    without fold12 (f16) and for the f32 instantiation; one launch less; the float32-input entry point (no byte LUT) keeps
+    the two kernels."""
     crops = np.concatenate([golden["crops"], synth.scene_crops(13, seed=31)])          # 21 crops
     with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
         k1 = h.info().n_kernels_per_forward
@@ -357,10 +358,21 @@ def test_stem_fused_with_block_1_depthwise_is_bitwise_the_two_kernels(blob, gold
         finally:
             h.device_free(d)
         assert "whenet_stemdw_kernel" in names and not any("whenet_dw_kernel" in k or "whenet_stem_mfma" in k for k in names)
-    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:
-        k = h.info().n_kernels_per_forward
+    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h:           # the f32 instantiation (exact-f32 matrix-core stem)
+        k1 = h.info().n_kernels_per_forward
+        y1, a1, l1 = h.forward(crops)
         h.set_option("stem_fuse", 0)
-        assert h.info().n_kernels_per_forward == k           # f32 handles: never fused
+        assert h.info().n_kernels_per_forward == k1 + 1
+        y0, a0, l0 = h.forward(crops)
+        assert np.array_equal(l1, l0) and np.array_equal(y1, y0) and np.array_equal(a1, a0)
+        h.set_option("stem_fuse", 1)
+        for lo, hi in ((0, 1), (1, 3), (4, 21)):
+            y, a, l = h.forward(crops[lo:hi])
+            assert np.array_equal(l, l1[lo:hi]) and np.array_equal(y, y1[lo:hi]), (lo, hi)
+        # real-valued (already normalised) crops have no byte LUT: that entry point keeps the two kernels
+        xf = O.normalise(crops[:3]).astype(np.float32)
+        yf, af, lf = h.forward_f32(xf)
+        assert np.abs(lf - l1[:3]).max() < 1e-3
 
 
 def test_decode_kernel(handle):

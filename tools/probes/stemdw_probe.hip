@@ -1,7 +1,7 @@
 // Probe for stemdw.hip: the fused stem + block-1 depthwise kernel against stem.hip followed by dw.hip on random bytes --
 // bitwise comparison of the depthwise output and the per-tile channel sums (first mismatches are printed), and timing
 // at 256 / 64 / 16 / 1 crops.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWHENET_STAMPS] -Iinclude tools/probes/stemdw_probe.hip -o tools/probes/stemdw_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DWHENET_STAMPS] [-DPROBE_F32] -Iinclude tools/probes/stemdw_probe.hip -o tools/probes/stemdw_probe
 #define WHENET_STEMDW_DEBUG 1
 #include "../../headposeestimation-whenet_amd/csrc/stem.hip"
 #include "../../headposeestimation-whenet_amd/csrc/dw.hip"
@@ -12,6 +12,11 @@
 #include <vector>
 
 using namespace whenet;
+#ifdef PROBE_F32
+using AT = float; constexpr int DT = WHENET_F32;
+#else
+using AT = half_t; constexpr int DT = WHENET_F16;
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 static float frand(float s) { return s * (float(rand() % 2001) / 1000.f - 1.f); }
 template <typename T> T* upload(const std::vector<T>& h) {
@@ -43,32 +48,35 @@ int main() {
     StemDwTable htab; build_stemdw_table(w.data(), lut.data(), &htab);
     StemDwTable* d_tab; CK(hipMalloc(&d_tab, sizeof(htab))); CK(hipMemcpy(d_tab, &htab, sizeof(htab), hipMemcpyHostToDevice));
     const size_t act = size_t(NMAX) * 112 * 112 * 32;
-    half_t *d_stem, *d_dw0, *d_dw1; float *d_p0, *d_p1;
-    CK(hipMalloc(&d_stem, act * 2)); CK(hipMalloc(&d_dw0, act * 2)); CK(hipMalloc(&d_dw1, act * 2));
+    AT *d_stem, *d_dw0, *d_dw1; float *d_p0, *d_p1;
+    CK(hipMalloc(&d_stem, act * sizeof(AT))); CK(hipMalloc(&d_dw0, act * sizeof(AT))); CK(hipMalloc(&d_dw1, act * sizeof(AT)));
     CK(hipMalloc(&d_p0, size_t(NMAX) * 56 * 32 * 4)); CK(hipMalloc(&d_p1, size_t(NMAX) * 56 * 32 * 4));
     hipStream_t st; CK(hipStreamCreate(&st));
-    const DwPlan plan = plan_dw(WHENET_F16, 3, 1, 112, 112, 32);
+    const DwPlan plan = plan_dw(DT, 3, 1, 112, 112, 32);
     printf("plan: threads %d CV %d TH %d NSX %d tiles %d x %d chunks %d -> stemdw_supported %d\n", plan.threads, plan.CV, plan.TH, plan.NSX,
-           plan.tiles_x, plan.tiles_y, plan.chunks, int(stemdw_supported(WHENET_F16, plan, 3, 1, 112, 32)));
+           plan.tiles_x, plan.tiles_y, plan.chunks, int(stemdw_supported(DT, plan, 3, 1, 112, 32)));
     auto two = [&](int n) {
         StemArgs a{d_img, d_stem, d_w, d_b, d_lut, n};
-        launch_stem(a, WHENET_F16, st);
+        launch_stem(a, DT, st);
         DwArgs d{};
         d.in = d_stem; d.out = d_dw0; d.w = d_wd; d.bias = d_bd; d.partial = d_p0; d.k = 3; d.s = 1; d.H = 112; d.Ho = 112; d.C = 32; d.pad = 1;
         d.n = n; d.plan = plan;
-        launch_dw(d, WHENET_F16, st);
+        launch_dw(d, DT, st);
     };
     auto one = [&](int n) {
-        StemDwArgs a{d_img, d_dw1, d_tab, d_b, d_wd, d_bd, d_p1, n};
+        StemDwArgs a{DT, d_img, d_dw1, d_tab, d_w, d_lut, d_b, d_wd, d_bd, d_p1, n};
         launch_stemdw(a, st);
     };
     const int NCHK = 3;
-    CK(hipMemset(d_dw1, 0xff, act * 2));
+    CK(hipMemset(d_dw1, 0xff, act * sizeof(AT)));
+#ifndef PROBE_F32
     half_t* d_sdbg; CK(hipMalloc(&d_sdbg, size_t(NCHK) * 112 * 112 * 32 * 2));
     CK(hipMemset(d_sdbg, 0xff, size_t(NCHK) * 112 * 112 * 32 * 2));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stemdw_dbg), &d_sdbg, sizeof(d_sdbg)));
+#endif
     two(NCHK); one(NCHK);
     CK(hipStreamSynchronize(st));
+#ifndef PROBE_F32
     {
         half_t* nul = nullptr;
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stemdw_dbg), &nul, sizeof(nul)));
@@ -84,15 +92,20 @@ int main() {
             }
         printf("stem values: %zu of %zu differ\n", sb, s0.size());
     }
+#endif
+#ifdef PROBE_F32
+    std::vector<uint32_t> h0(size_t(NCHK) * 112 * 112 * 32), h1(h0.size());
+#else
     std::vector<uint16_t> h0(size_t(NCHK) * 112 * 112 * 32), h1(h0.size());
-    CK(hipMemcpy(h0.data(), d_dw0, h0.size() * 2, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(h1.data(), d_dw1, h1.size() * 2, hipMemcpyDeviceToHost));
+#endif
+    CK(hipMemcpy(h0.data(), d_dw0, h0.size() * sizeof(AT), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h1.data(), d_dw1, h1.size() * sizeof(AT), hipMemcpyDeviceToHost));
     size_t bad = 0;
     for (size_t i = 0; i < h0.size(); ++i)
         if (h0[i] != h1[i]) {
             if (bad < 12) {
                 const int c = int(i % 32), x = int((i / 32) % 112), y = int((i / 32 / 112) % 112), n = int(i / 32 / 112 / 112);
-                printf("  mismatch crop %d y %3d x %3d c %2d: two %04x one %04x\n", n, y, x, c, h0[i], h1[i]);
+                printf("  mismatch crop %d y %3d x %3d c %2d: two %08x one %08x\n", n, y, x, c, unsigned(h0[i]), unsigned(h1[i]));
             }
             ++bad;
         }
