@@ -16,6 +16,11 @@ for LB in 64 32; do
   python tools/pmc_summary.py gpurun_out/pmc_f16_b64_c${LB}_p profiles/$RND/pmc_traffic_f16_b64.json $LB > $R/gpurun_out/final/pmc_f16_b64_c${LB}_by_kernel.txt 2>&1; echo "pmc summary exit $?"
 done
 cp profiles/$RND/pmc_traffic_f16_b64.json $R/gpurun_out/final/
+# the parity configuration's chain (one chain of 64 crops)
+rm -f $R/profiles/$RND/pmc_traffic_f32_b64.json
+bash tools/pmc_round.sh f32 64 64 > $R/gpurun_out/final/pmc_f32_c64.log 2>&1; echo "pmc f32 exit $?"
+python tools/pmc_summary.py gpurun_out/pmc_f32_b64_c64_p profiles/$RND/pmc_traffic_f32_b64.json 64 > $R/gpurun_out/final/pmc_f32_b64_c64_by_kernel.txt 2>&1; echo "pmc f32 summary exit $?"
+cp profiles/$RND/pmc_traffic_f32_b64.json $R/gpurun_out/final/
 timeout 600 python bench.py --dump-layers $R/gpurun_out/final/layers_default.json > $R/gpurun_out/final/bench_default.json 2> $R/gpurun_out/final/bench_default.err; echo "bench exit $?"
 # the driver's own command line (20 timed steps: the region is repeated, the median is the value)
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $R/gpurun_out/final/bench_driver_args.json 2> /dev/null; echo "bench (driver args) exit $?"
@@ -27,6 +32,8 @@ timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-latency --no-sweep 
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/final/rocprof_stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats -o bench -- python $R/bench.py --no-cpu-baseline --no-latency --no-serial --no-sweep > $R/gpurun_out/final/rocprof_bench.json 2>/dev/null; echo "rocprof exit $?"
+rm -rf $R/gpurun_out/final/rocprof_stats_f32
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats_f32 -o bench -- python $R/bench.py --dtype f32 --no-cpu-baseline --no-latency --no-serial --no-sweep > /dev/null 2>&1; echo "rocprof f32 exit $?"
 rm -rf $R/gpurun_out/final/rocprof_stats_b512
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats_b512 -o bench -- python $R/bench.py --batch 512 --inflight 1 --no-cpu-baseline --no-latency --no-serial --no-sweep > /dev/null 2>&1; echo "rocprof b512 exit $?"
 cd $R && python tools/gpu_diag.py --quick > $R/gpurun_out/final/diag.txt 2>&1; echo "diag exit $?"
