@@ -125,6 +125,15 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                        ? *reinterpret_cast<const VT*>(k.xrow + (ks + u) * 2 * V)
                        : vec_zero<T>();
     };
+    auto load_half = [&](const Task& k, int ks, int u0, VT (&w)[PF], VT (&a)[PF]) {      // k-steps ks, ks + 1 -> slots u0, u0 + 1
+#pragma unroll
+        for (int u = 0; u < PF / 2; ++u) w[u0 + u] = (ks + u < KSe) ? k.wf[(ks + u) * NTe * 64] : vec_zero<T>();
+#pragma unroll
+        for (int u = 0; u < PF / 2; ++u)
+            a[u0 + u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
+                            ? *reinterpret_cast<const VT*>(k.xrow + (ks + u) * 2 * V)
+                            : vec_zero<T>();
+    };
     auto load_bias = [&](const Task& k, float4v (&bv)[4]) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -170,12 +179,20 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // Round 4: (1) k-steps past KSe are not multiplied (their operands are zeros: same sum; in f32 a k-step is four 64-cycle
+        // MFMAs and Cin = 16 / 24 / 40 fill 2 / 3 / 5 of 4 / 4 / 8 slots); (2) deep contractions are pipelined in the SAME
+        // registers: while one half of the PF slots is multiplied the other half's next k-steps travel (round 3 loaded a whole
+        // group and waited for it before every 4 k-steps).
+        constexpr int HF = PF / 2;
+        for (int ks = 0; ks < KSe; ks += PF) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) Mfma<T>::step(w[u], a[u], acc);
-        for (int ks = PF; ks < KSe; ks += PF) {
-            load_ops(cur, ks, w, a);
+            for (int u = 0; u < HF; ++u)
+                if (ks + u < KSe) Mfma<T>::step(w[u], a[u], acc);           // (wave-uniform)
+            if (ks + PF < KSe) load_half(cur, ks + PF, 0, w, a);
 #pragma unroll
-            for (int u = 0; u < PF; ++u) Mfma<T>::step(w[u], a[u], acc);
+            for (int u = HF; u < PF; ++u)
+                if (ks + u < KSe) Mfma<T>::step(w[u], a[u], acc);
+            if (ks + PF + HF < KSe) load_half(cur, ks + PF + HF, HF, w, a);
         }
         const Task nxt = make_task(t + NWAVE);
         if (t + NWAVE < ntask) load_ops(nxt, 0, w, a);
