@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                                                              int NCH, const SeFuse se) {
     constexpr bool GATE = GM != 0;
     constexpr int TGK = 256;                                // K < 320 here: block 6's 240 is the widest gated layer
-    __shared__ __attribute__((aligned(16))) T s_gate[GM == 2 ? 2 * TGK : 8];     // 128 rows touch <= 2 crops (HW >= 196)
+    __shared__ __attribute__((aligned(16))) T s_gate[GATE ? 2 * TGK : 8];        // 128 rows touch <= 2 crops (HW >= 196)
     __shared__ float s_r[GM == 2 ? 2 * 12 : 4];
     constexpr int V = Vec<T>::V;
     using VT = typename Vec<T>::type;
@@ -307,10 +307,10 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     const int rowc = rvalid ? row : (M - 1);
 
     const T* ap = A + size_t(rowc) * K + g * V;
-    const T* gp = nullptr;
     const int crop_lo = (mt * 128) / HW;
-    if constexpr (GM == 1) gp = gate + size_t(rowc / HW) * K + g * V;
-    if constexpr (GM == 2) gp = s_gate + (rowc / HW - crop_lo) * K + g * V;        // (LDS)
+    // the gate rows of this workgroup's <= 2 crops live in LDS for both gated forms (round 4: GM = 1 read them from global
+    // memory next to every activation fragment -- and multiplied at once, so each prefetched k-step waited for two loads)
+    const T* gp = GATE ? s_gate + (rowc / HW - crop_lo) * K + g * V : nullptr;
     const VT* wsrc = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64;
 
     float16v acc[NT];
@@ -319,19 +319,25 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+    // Round 4: every global load of the k-loop is UNCONDITIONAL (k-steps past KS and tiles past NTILES read a clamped address and are
+    // never multiplied; rows past M repeat row M - 1 and are never stored), the gate is applied when a fragment is CONSUMED, not when
+    // it is requested.  Before, the loads sat under per-lane conditions (the compiler waits with vmcnt(0) then) and the gate
+    // multiply right behind each load made the "prefetch" of a group four dependent round trips.
+    const bool ktail = K % (2 * V) != 0 && g == 1;          // (only un-gated expand convs with Cin = 24 / 40 have one)
     auto load_raw = [&](int ks) -> VT {
-        VT a = vec_zero<T>();
-        if (rvalid && ks < KS && ks * 2 * V + g * V < K) a = *reinterpret_cast<const VT*>(ap + ks * 2 * V);
+        const int kc = ks < KS ? ks : KS - 1;
+        VT a = *reinterpret_cast<const VT*>(ap + (ktail && kc == KS - 1 ? -g * V : 0) + kc * 2 * V);
+        if (ktail && kc == KS - 1) a = vec_zero<T>();       // (the bytes past the row; their weights are zero, the bytes may be anything)
         return a;
     };
     auto gated = [&](VT a, int ks) -> VT {
         if constexpr (GATE)
-            if (rvalid && ks < KS && ks * 2 * V + g * V < K) a = a * *reinterpret_cast<const VT*>(gp + ks * 2 * V);   // T x T, one rounding
+            if (ks < KS) a = a * *reinterpret_cast<const VT*>(gp + ks * 2 * V);   // T x T, one rounding (LDS)
         return a;
     };
-    auto load_a = [&](int ks) -> VT { return gated(load_raw(ks), ks); };
 
     VT wreg[CPT];
+    static_assert(STAGE_VECS % 256 == 0, "every lane stages whole vectors");
     auto fetch_w = [&](int grp) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
             const int u = i / (NT * 64);
             const int j = i - u * (NT * 64);
             const int ks = grp * UK + u;
-            wreg[c] = (i < STAGE_VECS && ks < KS && nt0 + (j >> 6) < NTILES) ? wsrc[size_t(ks) * NTILES * 64 + j]
-                                                                              : vec_zero<T>();
+            const int jc = nt0 + (j >> 6) < NTILES ? j : (j & 63);
+            wreg[c] = wsrc[size_t(ks < KS ? ks : KS - 1) * NTILES * 64 + jc];
         }
     };
     auto store_w = [&](int buf) {
@@ -356,22 +362,25 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     fetch_w(0);
 #pragma unroll
     for (int u = 0; u < UK; ++u) areg[u] = load_raw(u);
-    if constexpr (GM == 2) {                                // the gate of this workgroup's <= 2 crops, while the first
-        const int row_last = (mt * 128 + 128 < M ? mt * 128 + 128 : M) - 1;        // operands travel
-        se_fused_to_lds<T, 256>(se, crop_lo, row_last / HW - crop_lo + 1, K, s_gate, s_r);
+    const int row_last = (mt * 128 + 128 < M ? mt * 128 + 128 : M) - 1;
+    if constexpr (GM == 1) {                                // the gate rows of the <= 2 crops -> LDS (16 bytes per lane)
+        const int cnt = (row_last / HW - crop_lo + 1) * K / V;
+        const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
+        for (int i = tid; i < cnt; i += 256) reinterpret_cast<VT*>(s_gate)[i] = src[i];
     }
-#pragma unroll
-    for (int u = 0; u < UK; ++u) areg[u] = gated(areg[u], u);
+    if constexpr (GM == 2)                                  // ... or computed from the producer's squeeze-excite partial vectors
+        se_fused_to_lds<T, 256>(se, crop_lo, row_last / HW - crop_lo + 1, K, s_gate, s_r);
     store_w(0);
     __syncthreads();
-    for (int grp = 0; grp < G; ++grp) {
-        const bool more = grp + 1 < G;
-        VT anext[UK];
-        if (more) {
-            fetch_w(grp + 1);
 #pragma unroll
-            for (int u = 0; u < UK; ++u) anext[u] = load_a((grp + 1) * UK + u);
-        }
+    for (int u = 0; u < UK; ++u) areg[u] = gated(areg[u], u);
+    for (int grp = 0; grp < G; ++grp) {
+        // (the last iteration requests a group that does not exist: clamped addresses, an LDS buffer nobody reads -- straight-line
+        //  code, so that the compiler counts what is outstanding)
+        VT anext[UK];
+        fetch_w(grp + 1);
+#pragma unroll
+        for (int u = 0; u < UK; ++u) anext[u] = load_raw((grp + 1) * UK + u);
         const VT* wl = s_w + (grp & 1) * STAGE_VECS + lane;
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
@@ -381,12 +390,10 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                     if (nt0 + t < NTILES) Mfma<T>::step(wl[(u * NT + t) * 64], areg[u], acc[t]);
             }
         }
-        if (more) {
-            store_w((grp + 1) & 1);
+        store_w((grp + 1) & 1);
 #pragma unroll
-            for (int u = 0; u < UK; ++u) areg[u] = anext[u];
-        }
-        __syncthreads();
+        for (int u = 0; u < UK; ++u) areg[u] = gated(anext[u], (grp + 1) * UK + u);
+        lds_barrier();                                      // (LDS only: nothing else is exchanged here)
     }
 
     // ---- epilogue: bias / activation in f32, LDS transpose, 16-byte row-contiguous stores ----
@@ -586,6 +593,8 @@ void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t st
     WHENET_REQUIRE(!(a.gate != nullptr && a.se.rpart != nullptr), WHENET_EINVAL, "pointwise: gate AND fused squeeze-excite");
     WHENET_REQUIRE(!gated || a.K < 320 || (a.K <= 1152 && a.K % 16 == 0 && a.HW >= 49), WHENET_EINVAL,
                    "pointwise: gated deep contraction outside the staged-gate limits (K <= 1152, K % 16 == 0, HW >= 49)");
+    WHENET_REQUIRE(!gated || a.K >= 320 || (a.K <= 256 && a.HW >= 196), WHENET_EINVAL,
+                   "pointwise: gated shallow contraction outside the staged-gate limits (K <= 256, HW >= 196)");
     WHENET_REQUIRE(a.se.rpart == nullptr || (a.se.RP % 4 == 0 && a.se.RP <= 48 && a.se.np >= 1 &&
                                              (a.K >= 320 || (a.K <= 256 && a.HW >= 196 && a.se.RP <= 12))),
                    WHENET_EINVAL, "pointwise: fused squeeze-excite outside its limits");
