@@ -193,14 +193,19 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     // bytes past a pixel row are the next pixel's channels -- or, for the last pixel of the last crop, whatever follows
     // the tensor: 0 x NaN would poison the accumulators, so those lanes' operand is zeroed (one v_cndmask per dword on
     // the last k-step of the two layers concerned; same bits wherever the bytes were finite)
+    // ... applied where the operand is CONSUMED (zero_ktail below, right in front of its MFMA): a select behind the load makes
+    // the wave wait for the operands of the NEXT task the moment it has requested them (round 4, from the ISA: s_waitcnt
+    // vmcnt(1) + 4 v_cndmask right behind the prefetch of every task of every front2 launch)
     const bool ktail = (Cin & 15) != 0 && g == 1;
     auto load_a = [&](half8 (&a)[PF], unsigned off, int ks0) {
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            if (ks0 + u < KS) {
-                a[u] = *reinterpret_cast<const half8*>(xb + off + (ks0 + u) * 32);
-                if (ks0 + u == KS - 1 && ktail) a[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
+            if (ks0 + u < KS) a[u] = *reinterpret_cast<const half8*>(xb + off + (ks0 + u) * 32);
+    };
+    auto zero_ktail = [&](half8 (&a)[PF], int ks0) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (ks0 + u == KS - 1 && ktail) a[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
     };
     STAMP(0);
     int tl = 0, rb = 0, cbk = 0;                               // the task being computed
@@ -252,11 +257,13 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias_cur;        // (this lane's channel: BN bias as the initial value)
+        zero_ktail(aq[d], 0);
 #pragma unroll
         for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[u], acc, 0, 0, 0);
 #pragma unroll
         for (int ks = PF; ks < KS; ks += PF) {
             load_a(aq[d], aoffq[d], ks);
+            zero_ktail(aq[d], ks);
 #pragma unroll
             for (int u = 0; u < PF; ++u)
                 if (ks + u < KS) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[ks + u], acc, 0, 0, 0);
