@@ -397,9 +397,42 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     }
 
     // ---- epilogue: bias / activation in f32, LDS transpose, 16-byte row-contiguous stores ----
+    // Round 4: the bias vectors of a stage and the skip rows its lanes will add are requested TOGETHER at the top of the stage
+    // (unconditionally, from clamped addresses): the epilogue used to load each of the 4 bias vectors, and then each of the up to
+    // 4 skip pieces, under a condition right in front of its use -- eight dependent round trips per stage and wave.
     float* s_e = smem + wave * 32 * SROW;                   // aliases s_w: every wave is past the last barrier
 #pragma unroll
     for (int t0 = 0; t0 < NT; t0 += TPS) {
+        // 16-byte chunks of this stage that exist (narrow layers: N = 16 has 2 per row, not 8): the lanes walk
+        // only those, so a 16-channel project conv stores in one pass instead of four quarter-empty ones
+        int vc = N - (nt0 + t0) * 32;
+        vc = (vc > SW ? SW : vc);
+        vc = (vc > (NT - t0) * 32 ? (NT - t0) * 32 : vc) / CW;
+        const int vcs = vc > 0 ? vc : 1;                    // (a stage past the layer's last tile: nothing is stored, the requests
+        const float rvc = __builtin_amdgcn_rcpf(float(vcs));    //  below still need addresses inside the tensors)
+        float4v bvs[TPS][4];
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int n = (nt0 + t0 + tt) * 32 + 8 * qq + 4 * g;
+                bvs[tt][qq] = *reinterpret_cast<const float4v*>(bias + (n < N ? n : 0));
+            }
+        int sr[4], sch[4];
+        VT rvs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            const int r = int((float(idx) + 0.5f) * rvc);                         // idx / vc, exact (see front.hip)
+            sr[i] = r;
+            sch[i] = idx - r * vcs;
+            if constexpr (RES) {
+                int rowc2 = m0 + (r < 32 ? r : 31);
+                rowc2 = rowc2 < M ? rowc2 : M - 1;
+                const int nc = vc > 0 ? (nt0 + t0) * 32 + sch[i] * CW : 0;
+                rvs[i] = *reinterpret_cast<const VT*>(res + size_t(rowc2) * N + nc);
+            }
+        }
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) {
             const int t = t0 + tt;
@@ -408,33 +441,22 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                 for (int qq = 0; qq < 4; ++qq) {
                     const int n = (nt0 + t) * 32 + 8 * qq + 4 * g;
                     float4v y;
-                    if (n < N) {
-                        const float4v bv = *reinterpret_cast<const float4v*>(bias + n);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = acc[t < NT ? t : 0][4 * qq + r] + bv[r];
-                            if constexpr (ACT == ACT_SWISH) v = conv_swish<T>(v);
-                            y[r] = v;
-                        }
-                    } else {
-                        y = float4v{0.f, 0.f, 0.f, 0.f};
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[t < NT ? t : 0][4 * qq + r] + bvs[tt][qq][r];
+                        if constexpr (ACT == ACT_SWISH) v = conv_swish<T>(v);
+                        y[r] = (n < N) ? v : 0.f;
                     }
                     *reinterpret_cast<float4v*>(s_e + (lane & 31) * SROW + tt * 32 + 8 * qq + 4 * g) = y;
                 }
             }
         }
         lds_barrier();
-        // 16-byte chunks of this stage that exist (narrow layers: N = 16 has 2 per row, not 8): the lanes walk
-        // only those, so a 16-channel project conv stores in one pass instead of four quarter-empty ones
-        int vc = N - (nt0 + t0) * 32;
-        vc = (vc > SW ? SW : vc);
-        vc = (vc > (NT - t0) * 32 ? (NT - t0) * 32 : vc) / CW;
-        const float rvc = __builtin_amdgcn_rcpf(float(vc));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i;
             if (i * 64 >= 32 * vc) break;                           // (wave-uniform)
-            const int r = int((float(idx) + 0.5f) * rvc), ch = idx - r * vc;      // idx / vc, exact (see front.hip)
+            const int r = sr[i], ch = sch[i];
             const int n = (nt0 + t0) * 32 + ch * CW;
             const int rowg = m0 + r;
             if (idx < 32 * vc && rowg < M) {
@@ -446,9 +468,8 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                     for (int j = 0; j < 4; ++j) y[c4 + j] = v[j];
                 }
                 if constexpr (RES) {
-                    const VT rv = *reinterpret_cast<const VT*>(res + size_t(rowg) * N + n);
 #pragma unroll
-                    for (int j = 0; j < CW; ++j) y[j] += float(rv[j]);
+                    for (int j = 0; j < CW; ++j) y[j] += float(rvs[i][j]);
                 }
                 *reinterpret_cast<VT*>(out + size_t(rowg) * N + n) = float_to_vec<T>(y);
             }
