@@ -151,8 +151,13 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     // activation operands of D tasks are in flight (a ring of D register sets).  Measured: D = 4 / 2 for the shallow
     // layers (Cin = 16 / 24..40) changes nothing (b2: 59.1 vs 56.1 us at 64 crops) -- the ~0.6 us a task takes there is
     // not operand latency but the wave's own issue rate (one VALU instruction per ~5 cycles at 2 - 3 waves per SIMD)
-    // plus the exposed FIRST load of the workgroup; so one task ahead it is.
-    constexpr int D = 1;
+    // plus the exposed FIRST load of the workgroup; so one task ahead it is.  (Re-measured at the end of round 4, after the stall
+    // behind the prefetch was gone -- tools/build_variant.sh ring2 front2.hip -DWHENET_F2_RING=2: default line 154.9 / 152.5 / 148.6 k
+    // crops/s for 1 / 2 / 3 tasks ahead, the deeper rings cost registers on the 14 x 14 layers.)
+#ifndef WHENET_F2_RING
+#define WHENET_F2_RING 1
+#endif
+    constexpr int D = WHENET_F2_RING;
     half8 w[KS], aq[D][PF];
     float bias_cur = 0.f;
     // The folded block-1 project (engine.cpp, option fold12): the expand's input is the PREVIOUS block's gated
