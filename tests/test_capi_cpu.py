@@ -52,6 +52,19 @@ def test_depthwise_plans_are_valid(dtype):
         assert p["lds_bytes"] >= p["IH"] * p["IW"] * cc * esz + b.k * b.k * cc * 4
 
 
+@pytest.mark.parametrize("dtype", [_lib.F32, _lib.F16])
+def test_depthwise_plans_keep_whole_cache_lines_and_block_1_is_the_fused_stem_tile(dtype):
+    """Round 4 (host logic of csrc/dw.hip plan_dw): block 1 -- the one depthwise launch of the default forward -- keeps a pixel's
+    32 channels in ONE chunk (its f32 plan used to be two 64-byte chunks of the 128-byte pixel: every cache line fetched by two
+    workgroups, 222 MB for a 103 MB input), and that plan is the tile stemdw.hip is built for (16 x 14 outputs, 256 lanes) --
+    otherwise the forward silently falls back to two launches.  (Sub-line chunks are penalised, not forbidden: the 5x5 stride-2
+    layers of the un-fused schedule still take them when nothing else fits the LDS budget.)"""
+    esz = 2 if dtype == _lib.F16 else 4
+    p1 = _lib.dw_plan(dtype, 1)
+    assert (p1["threads"], p1["TH"], p1["NSX"], p1["tiles_x"], p1["tiles_y"], p1["chunks"]) == (256, 16, 2, 8, 7, 1), p1
+    assert p1["CV"] * 16 == 32 * esz
+
+
 def test_create_error_codes(weights, tmp_path):
     # missing file -> OSError (Keras: OSError), garbage -> ValueError, truncated -> ValueError
     with pytest.raises(OSError):
