@@ -254,6 +254,12 @@ int whenet_frame_rects(int frame_h, int frame_w, const float* bboxes, int k, int
     return WHENET_OK;
 }
 
+int whenet_normalise_table(float lut[768]) {
+    if (lut == nullptr) return WHENET_EINVAL;
+    whenet::normalise_table(reinterpret_cast<float (*)[256]>(lut));
+    return WHENET_OK;
+}
+
 int whenet_submit_frame(whenet_t* h, const uint8_t* frame, int frame_h, int frame_w, int channel_order,
                         const int32_t* rects, int k, int* ticket) {
     if (ticket == nullptr || (channel_order != WHENET_RGB && channel_order != WHENET_BGR)) return WHENET_EINVAL;

@@ -5,6 +5,20 @@
 
 namespace whenet {
 
+// whenet.py:23-26: img/255 then (img-mean)/std in float64; Keras casts to float32 (whenet.py:27).
+void normalise_table(float lut[3][256]) {
+    const double mean[3] = {0.485, 0.456, 0.406};
+    const double stdv[3] = {0.229, 0.224, 0.225};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile double x = double(v) / 255.0;
+            volatile double y = x - mean[c];
+            volatile double z = y / stdv[c];
+            lut[c][v] = float(z);
+        }
+}
+
+
 namespace {
 
 struct Reader {
@@ -173,16 +187,7 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
         else m.params_backbone += int64_t(kv.second.count);
     }
 
-    // whenet.py:23-26: img/255 then (img-mean)/std in float64; Keras casts to float32.
-    const double mean[3] = {0.485, 0.456, 0.406};
-    const double stdv[3] = {0.229, 0.224, 0.225};
-    for (int c = 0; c < 3; ++c)
-        for (int v = 0; v < 256; ++v) {
-            volatile double x = double(v) / 255.0;
-            volatile double y = x - mean[c];
-            volatile double z = y / stdv[c];
-            m.lut[c][v] = float(z);
-        }
+    normalise_table(m.lut);
 
     {   // stem: Conv2D(32, 3x3, s2, same, no bias) + BN  -> [27][32]
         const float* w = need(t, "stem/conv/kernel", {3, 3, 3, 32}).data;

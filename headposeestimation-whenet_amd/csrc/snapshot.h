@@ -58,6 +58,9 @@ struct HostBlock {
     HostPw project;
 };
 
+// whenet.py:23-26 for every byte value and channel: float64 arithmetic, one rounding to float32 (Keras' cast, :27).
+void normalise_table(float lut[3][256]);
+
 struct HostModel {
     int dtype = WHENET_F32;
     float lut[3][256];               // whenet.py:23-26 for every byte value, per channel

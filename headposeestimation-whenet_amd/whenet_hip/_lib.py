@@ -50,6 +50,7 @@ _PROTOS = {
     "whenet_submit_u8": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "whenet_collect": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "whenet_frame_rects": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P]),
+    "whenet_normalise_table": (C.c_int, [_P]),
     "whenet_submit_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "whenet_op_crop_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "whenet_yolo_eval": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -127,6 +128,14 @@ def frame_rects(frame_h: int, frame_w: int, bboxes) -> np.ndarray:
     out = np.empty((b.shape[0], 4), np.int32)
     code = load().whenet_frame_rects(int(frame_h), int(frame_w), _ptr(b), b.shape[0], _ptr(out))
     raise_for(code, "whenet_frame_rects: bad arguments")
+    return out
+
+
+def normalise_lut() -> np.ndarray:
+    """[3,256] float32: whenet.py:23-26 + Keras' float32 cast for every byte value, as the stem kernels apply it.
+    Pure host arithmetic inside the library (no GPU needed)."""
+    out = np.empty((3, 256), np.float32)
+    raise_for(load().whenet_normalise_table(_ptr(out)), "whenet_normalise_table: bad arguments")
     return out
 
 

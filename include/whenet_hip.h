@@ -191,6 +191,10 @@ WHENET_API int whenet_collect(whenet_t* h, int ticket, float* ypr, int32_t* argm
 #define WHENET_RGB 0            /* frame is already RGB            (demo.py:8 converts first)       */
 #define WHENET_BGR 1            /* frame is BGR as cv2 delivers it (demo_video.py:22 swaps per crop) */
 WHENET_API int whenet_frame_rects(int frame_h, int frame_w, const float* bboxes, int k, int32_t* rects);
+/* whenet_normalise_table: the image of /root/reference/whenet.py:23-26 (`img/255`, `(img-mean)/std` in float64) followed by
+ * Keras' cast to float32 (whenet.py:27) for every byte value: lut[c*256 + v], c = R,G,B.  This is the table the stem
+ * kernels apply to uint8 crops.  Pure host arithmetic, no GPU needed. */
+WHENET_API int whenet_normalise_table(float lut[768]);
 /* frame uint8 [frame_h, frame_w, 3] (host).  Copies the frame into pinned memory and enqueues
  * H2D(frame) -> crop + colour order + cv2.resize-compatible bilinear to [k,224,224,3] on the device
  * -> forward -> D2H of the results; whenet_collect(ticket, ...) returns the k heads' outputs in

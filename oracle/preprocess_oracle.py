@@ -3,9 +3,12 @@
 TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's checker
 legs; the product (headposeestimation-whenet_amd/) never imports it.
 
-**Parity unpinned.**  The reference does this work with `cv2` (`opencv-python`, unpinned in
-/root/reference/requirements.txt:2), which is not installable here, and it holds no test or
-recorded output for it.  What is restated:
+**Parity: window arithmetic pinned to executed reference code, cv2.resize unpinned.**  The reference does the pixel
+work with `cv2` (`opencv-python`, unpinned in /root/reference/requirements.txt:2), which is not installable here, and
+it holds no test or recorded output for it.  The window arithmetic is the reference's own Python:
+demo_video.process_detection is EXECUTED on 1,220 float32 boxes with a frame object that records the slice it is
+asked for (tests/refharness.py -> tests/golden/reference_rects.npz) and crop_rect() must reproduce every window
+(tests/test_reference_run.py).  What is restated:
 
 * `enlarge_bbox`   /root/reference/demo_video.py:13-19  (the bbox margin arithmetic, float32
                    because YOLO's `sess.run` hands back float32 boxes -- yolo_postprocess.py:198-205

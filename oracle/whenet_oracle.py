@@ -1,14 +1,18 @@
 """CPU oracle for the WHENet hot path -- numpy, float64 by default.  TEST INFRASTRUCTURE.
 
-**Parity unpinned.**  The reference has no tests, no golden vectors and no recorded
-outputs for this path; its arithmetic lives in un-vendored third-party packages
-(``efficientnet==0.0.4`` on ``keras==2.1.6`` / ``tensorflow-gpu==1.12.0``,
-/root/reference/requirements.txt:3-5) that are not installable here, and the trained
-snapshot ``WHENet.h5`` is absent (/root/reference/.MISSING_LARGE_BLOBS:1).  This file is a
-restatement of the published algorithm anchored on the reference's own call sites; it is
-cross-checked against two independent implementations (oracle/whenet_torch.py, and the
-HuggingFace ``transformers`` EfficientNet in tests/test_oracle.py), not against the
-reference itself.
+**Parity: pinned to EXECUTED reference code for everything the reference wrote itself; the backbone is unpinned.**
+normalise(), softmax(), decode(), the head wiring and the batch_size=8 chunking are checked against what
+/root/reference/whenet.py:7-34 and utils.py:7-11 return when they are RUN (tests/refharness.py puts stand-ins for
+keras / efficientnet / cv2 into sys.modules; tests/golden/make_reference_fixtures.py commits the outputs as
+tests/golden/reference_get_angle.npz; tests/test_reference_run.py asserts oracle == reference-run output on CPU and the
+HIP path against the same arrays on the GPU).  What that run cannot cover is the body of ``efn.EfficientNetB0``: the
+reference has no tests, no golden vectors and no recorded outputs, its arithmetic lives in un-vendored third-party
+packages (``efficientnet==0.0.4`` on ``keras==2.1.6`` / ``tensorflow-gpu==1.12.0``,
+/root/reference/requirements.txt:3-5) that are not installable here, and the trained snapshot ``WHENet.h5`` is absent
+(/root/reference/.MISSING_LARGE_BLOBS:1).  backbone() is a restatement of the published algorithm anchored on the
+reference's call site (whenet.py:8); it is cross-checked against two independent implementations
+(oracle/whenet_torch.py, and the HuggingFace ``transformers`` EfficientNet in tests/test_oracle.py), not against the
+reference itself: **backbone parity unpinned**.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
 module.  The product path (headposeestimation-whenet_amd/) never does.

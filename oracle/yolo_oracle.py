@@ -3,9 +3,12 @@
 TEST INFRASTRUCTURE ONLY -- imported by tests/ and __graft_entry__.smoke(); the product
 (headposeestimation-whenet_amd/) never imports it.
 
-**Parity unpinned.**  The reference runs this as TensorFlow-1.12 graph ops inside `sess.run`
-(/root/reference/yolo_v3/yolo_postprocess.py:198-204); TensorFlow cannot be installed here and the
-reference records no detections.  What is restated, in float32 like the graph:
+**Parity: decode pinned to executed reference code, NMS unpinned.**  The reference runs this as TensorFlow-1.12 graph
+ops inside `sess.run` (/root/reference/yolo_v3/yolo_postprocess.py:198-204); TensorFlow cannot be installed here and
+the reference records no detections.  But yolo_v3/model.py:125-232 is Python over `keras.backend`: it is EXECUTED over a
+numpy float32 backend stand-in (tests/refharness.py) and its decoded boxes / scores / selections are committed as
+tests/golden/reference_yolo.npz; tests/test_reference_run.py asserts this module reproduces them.  Only
+`tf.image.non_max_suppression` (a C++ kernel) stays a restatement.  What is restated, in float32 like the graph:
 
 * `yolo_head`              /root/reference/yolo_v3/model.py:125-150  (grid, sigmoid/exp decode, anchors)
 * `yolo_correct_boxes`     /root/reference/yolo_v3/model.py:153-178  (letterbox offset/scale, y-first boxes,

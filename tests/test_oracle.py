@@ -4,7 +4,9 @@ these tests pin it the only ways available here:
   * an independent float32 torch/oneDNN restatement agrees to float32 noise,
   * an independent third-party implementation of EfficientNet-B0 (HuggingFace
     transformers, torch) fed the same weights produces the same 7x7x1280 features,
-  * the reference's own pre/post-processing lines restated literally.
+  * the reference's own pre/post-processing lines are EXECUTED, not restated: tests/test_reference_run.py
+    (whenet.py:22-34 and utils.py:7-11 run from /root/reference under module stand-ins; their outputs are the
+    committed fixtures tests/golden/reference_*.npz that the oracle -- and the HIP path -- are checked against).
 """
 import os
 
@@ -43,43 +45,6 @@ def test_numpy_f32_noise_floor(weights, golden):
     r = O.forward(golden["crops"][:4], weights, np.float32)
     ang = np.stack([r["yaw"], r["pitch"], r["roll"]], axis=1)
     assert np.abs(ang - golden["expected"]["angles"][:4]).max() < 1e-3
-
-
-def test_normalise_is_reference_arithmetic():
-    """whenet.py:23-26 literally, on every byte value; LUT == normalise()."""
-    v = np.arange(256, dtype=np.uint8)
-    img = np.zeros((1, 224, 224, 3), np.uint8)
-    img[0, 0, :256 - 32, :] = v[:224, None]
-    img[0, 1, :32, :] = v[224:, None]
-    mean = [0.485, 0.456, 0.406]
-    std = [0.229, 0.224, 0.225]
-    ref = ((img / 255 - mean) / std).astype(np.float32)
-    got = O.normalise(img)
-    assert np.array_equal(ref, got)
-    lut = O.normalise_lut()
-    assert np.array_equal(lut[np.arange(3)[None, None, None, :], img], got)
-
-
-def test_decode_is_reference_arithmetic():
-    """whenet.py:28-33 + utils.py:7-11 literally, float32 like the reference."""
-    rng = np.random.default_rng(3)
-    lg = rng.normal(0, 4, size=(5, 252)).astype(np.float32)
-
-    def ref_softmax(x):
-        x -= np.max(x, axis=1, keepdims=True)
-        a = np.exp(x)
-        b = np.sum(np.exp(x), axis=1, keepdims=True)
-        return a / b
-
-    idx = np.arange(66, dtype=np.float32)
-    idy = np.arange(120, dtype=np.float32)
-    yaw = np.sum(ref_softmax(lg[:, :120].copy()) * idy, axis=1) * 3 - 180
-    pitch = np.sum(ref_softmax(lg[:, 120:186].copy()) * idx, axis=1) * 3 - 99
-    roll = np.sum(ref_softmax(lg[:, 186:].copy()) * idx, axis=1) * 3 - 99
-    y, p, r = O.decode(lg)
-    for a, b in ((y, yaw), (p, pitch), (r, roll)):
-        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
-    assert y.min() >= -180 and y.max() <= 177 and p.min() >= -99 and p.max() <= 96
 
 
 def test_conv_same_padding_against_torch():

@@ -42,8 +42,9 @@ def test_resize_exact_2x_is_box_mean():
     assert np.array_equal(P.resize_linear_u8(src), want.astype(np.uint8))
 
 
-def test_bbox_margins_follow_the_reference_line_by_line():
-    # demo_video.py:13-19 by hand, float32: the second statement sees the moved y_min
+def test_bbox_margins_hand_worked_case():
+    # one box worked by hand (float32: the second statement sees the moved y_min).  The reference's OWN
+    # process_detection is executed on 1,220 boxes in tests/test_reference_run.py; this is only the readable example.
     f = np.float32
     y_min, x_min, y_max, x_max = f(100.5), f(200.25), f(300.75), f(380.5)
     e_ymin = y_min - abs(y_min - y_max) / f(10)

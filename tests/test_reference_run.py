@@ -1,0 +1,345 @@
+"""The reference's OWN code as the checker.
+
+tests/golden/reference_*.npz / reference_demo.json hold what /root/reference's own Python returned when it was
+executed under tests/refharness.py (generator: tests/golden/make_reference_fixtures.py):
+
+  whenet.py:7-34 + utils.py:7-11   WHENet.__init__ / get_angle / softmax, as written
+  demo_video.py:11-35              process_detection's window arithmetic, as written
+  yolo_v3/model.py:125-232         yolo_head / yolo_correct_boxes / yolo_boxes_and_scores / yolo_eval, as written
+  demo.py:19-30                    the demo's __main__, as written, against the drop-in class
+
+CPU tests here: (1) the restatements under oracle/ reproduce those reference-run outputs (so rows 8a2, 8a7, 8a8, the
+8f2 windows and the 8f4 decode rest on executed reference code, not on re-typed copies), (2) where /root/reference is
+present (build container), the reference is executed LIVE again and must reproduce the committed fixtures.
+GPU tests: the HIP path through the C ABI against the same fixtures (the GPU box has no /root/reference).
+
+What stays unpinned: the body of efn.EfficientNetB0 (third-party, absent), tf.image.non_max_suppression (TensorFlow's
+C++ kernel) and cv2.resize -- restatements, as every doc says.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import preprocess_oracle as P
+from oracle import whenet_oracle as O
+from oracle import yolo_oracle as Y
+from tests import refcases as C
+from tests import refharness as H
+from whenet_hip import _lib, synth
+
+GOLD = C.GOLDEN
+live = pytest.mark.skipif(not H.available(), reason="/root/reference is only present in the build container")
+
+
+@pytest.fixture(scope="module")
+def ref_angles():
+    return dict(np.load(os.path.join(GOLD, "reference_get_angle.npz")))
+
+
+@pytest.fixture(scope="module")
+def ref_rects():
+    return dict(np.load(os.path.join(GOLD, "reference_rects.npz")))
+
+
+@pytest.fixture(scope="module")
+def ref_yolo():
+    return dict(np.load(os.path.join(GOLD, "reference_yolo.npz")))
+
+
+@pytest.fixture(scope="module")
+def ref_demo():
+    with open(os.path.join(GOLD, "reference_demo.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def crops64(ref_angles):
+    c = C.crops64()
+    assert hashlib.sha256(c.tobytes()).hexdigest() == str(ref_angles["crops_sha256"])
+    return c
+
+
+def _argmax(lg):
+    return O.argmax_bins(lg)
+
+
+# =============================================================================== CPU: oracle == reference-run output
+def test_fixture_shapes_and_types(ref_angles):
+    for n in C.SIZES:
+        a = ref_angles[f"n{n}_angles"]
+        assert a.shape == (n, 3) and a.dtype == np.float32 and str(ref_angles[f"n{n}_dtype"]) == "float32"
+        assert ref_angles[f"n{n}_logits"].shape == (n, 252)
+    # whenet.py:27 chunks by 8; the chunking must not show: every N is a prefix of N=64, bitwise
+    for n in C.SIZES:
+        assert np.array_equal(ref_angles[f"n{n}_angles"], ref_angles["n64_angles"][:n])
+        assert np.array_equal(ref_angles[f"n{n}_logits"], ref_angles["n64_logits"][:n])
+
+
+def test_oracle_whole_path_equals_reference_run(weights, crops64, ref_angles):
+    """oracle.forward (the checker every GPU parity test uses) against WHENet.get_angle executed from
+    /root/reference/whenet.py: angles to float32 round-off (the reference decodes in float32, the oracle in
+    float64), logits to float32 round-off, argmax identical."""
+    r = O.forward(crops64[:16], weights, np.float64)
+    ang = np.stack([r["yaw"], r["pitch"], r["roll"]], axis=1)
+    ref = ref_angles["n64_angles"][:16]
+    assert np.abs(ang - ref).max() < 5e-5, np.abs(ang - ref).max()
+    assert np.abs(r["logits"] - ref_angles["n64_logits"][:16]).max() < 2e-5
+    assert np.array_equal(r["argmax"], _argmax(ref_angles["n64_logits"][:16]))
+
+
+def test_oracle_real_valued_input_equals_reference_run(weights, crops64, ref_angles):
+    x = C.real_valued(crops64)
+    assert x.min() < 0 and x.max() > 255 and not np.all(x == np.rint(x))
+    r = O.forward(x, weights, np.float64)
+    ang = np.stack([r["yaw"], r["pitch"], r["roll"]], axis=1)
+    assert np.abs(ang - ref_angles["real_angles"]).max() < 5e-5
+    assert np.array_equal(r["argmax"], _argmax(ref_angles["real_logits"]))
+
+
+def test_oracle_decode_equals_reference_softmax_and_expectation(ref_angles):
+    """utils.py:7-11 + whenet.py:28-33 were executed on these float32 logits; oracle.decode on the same float32
+    logits must agree to a float32 ulp of the angle range (same formula, numpy both sides)."""
+    lg = ref_angles["n64_logits"]
+    y, p, r = O.decode(lg)
+    got = np.stack([y, p, r], axis=1)
+    assert got.dtype == np.float32
+    assert np.abs(got - ref_angles["n64_angles"]).max() <= 3.1e-5          # 1 ulp at 180-256 deg = 1.5e-5
+    y, p, r = O.decode(lg.astype(np.float64))
+    assert np.abs(np.stack([y, p, r], axis=1) - ref_angles["n64_angles"]).max() < 5e-5
+
+
+def test_oracle_normalise_equals_reference_lines(ref_angles):
+    """whenet.py:23-26 executed on every byte value, after Keras' float32 cast: the 3x256 table."""
+    lut = ref_angles["normalise_lut"]
+    assert lut.shape == (3, 256) and lut.dtype == np.float32
+    assert np.array_equal(O.normalise_lut(), lut)
+    assert np.array_equal(C.lut_from_normalised(O.normalise(C.all_bytes_image())), lut)
+
+
+def test_product_lut_equals_reference_lines(ref_angles):
+    """the table the library folds into the stem (snapshot.cpp, float64 then one rounding) -- host code, CPU."""
+    lut = _lib.normalise_lut()
+    assert np.array_equal(lut, ref_angles["normalise_lut"])
+
+
+def test_oracle_windows_equal_process_detection(ref_rects):
+    b, hw, want = ref_rects["boxes"], ref_rects["frame_hw"], ref_rects["rects"]
+    assert len(b) >= 1000
+    got = np.array([P.crop_rect(int(h), int(w), r) for r, (h, w) in zip(b, hw)], np.int32)
+    assert np.array_equal(got, want)
+    # what the reference asked numpy for, before numpy clipped it, and what it drew (demo_video.py:26)
+    raw = ref_rects["slice_raw"]
+    assert np.array_equal(np.minimum(raw[:, 2:], hw), want[:, 2:]) and np.array_equal(raw[:, :2], want[:, :2])
+    assert np.array_equal(ref_rects["rectangle"][:, [1, 0, 3, 2]], raw)
+    # the cases that matter are in there: clipped at each edge, and the order dependence (lower margin > upper)
+    assert (want[:, 0] == 0).any() and (want[:, 1] == 0).any() and (want[:, 2] == hw[:, 0]).any() and (want[:, 3] == hw[:, 1]).any()
+
+
+def test_library_windows_equal_process_detection(ref_rects):
+    """whenet_frame_rects (host arithmetic inside libwhenet_hip.so) against the reference-run windows: bit-exact."""
+    b, hw, want = ref_rects["boxes"], ref_rects["frame_hw"], ref_rects["rects"]
+    for (h, w) in C.FRAMES:
+        sel = (hw[:, 0] == h) & (hw[:, 1] == w)
+        assert sel.sum() > 300
+        assert np.array_equal(_lib.frame_rects(h, w, b[sel]), want[sel])
+
+
+def _yolo_case(ref_yolo, i):
+    seed, nc, ih, iw, max_boxes = (int(v) for v in ref_yolo[f"case{i}_cfg"])
+    score, iou = (float(v) for v in ref_yolo[f"case{i}_thr"])
+    return synth.yolo_maps(seed, num_classes=nc), nc, (ih, iw), dict(max_boxes=max_boxes, score_threshold=score, iou_threshold=iou)
+
+
+@pytest.mark.parametrize("i", range(len(C.YOLO_CASES)))
+def test_oracle_yolo_equals_reference_run(ref_yolo, i):
+    assert np.array_equal(ref_yolo["anchors"], synth.YOLO_ANCHORS)          # yolo_v3/data/yolo_anchors.txt
+    maps, nc, image, kw = _yolo_case(ref_yolo, i)
+    b, s, c, idx = Y.yolo_eval(maps, synth.YOLO_ANCHORS, nc, image, return_index=True, **kw)
+    assert list(c) == list(ref_yolo[f"case{i}_classes"])
+    assert np.allclose(s, ref_yolo[f"case{i}_scores"], rtol=1e-6, atol=0)
+    assert np.allclose(b, ref_yolo[f"case{i}_boxes"], rtol=1e-6, atol=1e-3)
+    # every candidate the reference decoded (model.py:181-190), in yolo_eval's concatenation order
+    ab, asc = ref_yolo[f"case{i}_all_boxes"], ref_yolo[f"case{i}_all_scores"]
+    assert ab.shape == (10647, 4) and asc.shape == (10647, nc)
+    assert np.allclose(ab[idx], b, rtol=1e-6, atol=1e-3) and np.allclose(asc[idx, c], s, rtol=1e-6)
+    mask = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
+    ob, osc = zip(*[Y.yolo_boxes_and_scores(m, synth.YOLO_ANCHORS[mask[l]], nc, (416, 416), image) for l, m in enumerate(maps)])
+    assert np.allclose(np.concatenate(ob), ab, rtol=1e-6, atol=1e-3) and np.allclose(np.concatenate(osc), asc, rtol=1e-6, atol=1e-9)
+
+
+def test_demo_fixture(ref_demo):
+    """demo.py:19-30 ran against the drop-in class: one get_angle per Sample/ line, uint8 [1,224,224,3]
+    (demo.py:11-14), the rectangle of bbox.txt (demo.py:13), three axis lines per head (utils.py:43-45)."""
+    calls = ref_demo["forward_calls"]
+    assert [c[0] for c in calls] == [[1, 224, 224, 3]] * 2 and [c[1] for c in calls] == ["uint8"] * 2
+    assert ref_demo["rectangles"] == [[[240, 0], [304, 83]], [[116, 0], [280, 187]]]        # Sample/bbox.txt
+    assert ref_demo["n_lines"] == 6 and ref_demo["waitKey"] == [5000, 5000]                    # demo.py:17
+    z = np.load(os.path.join(GOLD, "sample_frames.npz"))
+    for i in range(2):      # the crop the demo fed == the committed crop of the same image (cv2 restatement both times)
+        assert hashlib.sha256(z[f"crop{i}"][None].tobytes()).hexdigest() == calls[i][3]
+
+
+# =============================================================================== CPU, live: execute the reference again
+@live
+def test_live_reference_get_angle_reproduces_fixture(weights, crops64, ref_angles):
+    y, p, r, m = H.run_get_angle(crops64[:9], weights, O.backbone)
+    assert m.model.predict_calls == [(9, 8)]
+    assert np.array_equal(np.stack([y, p, r], axis=1), ref_angles["n9_angles"])
+    assert np.array_equal(np.concatenate(m.model.last_outputs, axis=1), ref_angles["n9_logits"])
+
+
+@live
+def test_live_reference_softmax_and_decode_on_random_logits():
+    """utils.softmax / whenet.py:28-33 executed on logits the network never produces (ties, one-hot, huge)."""
+    rng = np.random.default_rng(3)
+    lg = rng.normal(0, 4, size=(16, 252)).astype(np.float32)
+    lg[1, :120] = 0
+    lg[2, :] = -50
+    lg[2, [7, 130, 200]] = 60
+    lg[3] *= 30
+    row = {"i": 0}
+
+    def backbone(x, ww):      # one chunk of <= 8 crops at a time: hand each crop its logits through the first 252 feature channels
+        n = x.shape[0]
+        f = np.zeros((n, 7, 7, 1280))
+        f[:, 0, 0, :252] = lg[row["i"]:row["i"] + n] * 49.0            # GAP divides by 49
+        row["i"] += n
+        return f
+
+    eye = np.zeros((1280, 252))
+    eye[:252] = np.eye(252)
+    w = {"yaw/kernel": eye[:, :120], "yaw/bias": np.zeros(120), "pitch/kernel": eye[:, 120:186], "pitch/bias": np.zeros(66),
+         "roll/kernel": eye[:, 186:], "roll/bias": np.zeros(66)}
+    y, p, r, m = H.run_get_angle(np.zeros((16, 224, 224, 3), np.uint8), w, backbone)
+    got_lg = np.concatenate(m.model.last_outputs, axis=1)
+    assert np.abs(got_lg - lg).max() < 1e-4
+    oy, op, orr = O.decode(got_lg)
+    for a, b in ((y, oy), (p, op), (r, orr)):
+        assert np.abs(a - b).max() <= 3.1e-5
+    assert y[1] == pytest.approx(59.5 * 3 - 180, abs=1e-4)                 # all-equal logits: the mean bin
+    assert (y[2], p[2], r[2]) == (7 * 3 - 180, 10 * 3 - 99, 14 * 3 - 99)  # one-hot
+
+
+@live
+def test_live_process_detection_reproduces_fixture(ref_rects):
+    class Args:
+        display = "simple"
+
+    class FakeModel:
+        def get_angle(self, img):
+            return np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros(1, np.float32)
+
+    with H.reference() as R:
+        dv = R.load("demo_video")
+        for k in range(0, len(ref_rects["boxes"]), 41):
+            h, w = (int(v) for v in ref_rects["frame_hw"][k])
+            frame = H.RecordingFrame(h, w)
+            dv.process_detection(FakeModel(), frame, ref_rects["boxes"][k], Args)
+            (sy, sx), = frame.slices
+            assert [sy.start, sx.start, sy.stop, sx.stop] == ref_rects["slice_raw"][k].tolist()
+
+
+@live
+def test_live_yolo_eval_reproduces_fixture(ref_yolo):
+    maps, nc, image, kw = _yolo_case(ref_yolo, 1)
+    with H.reference(nms_fn=Y.non_max_suppression) as R:
+        ym = R.load("yolo_v3.model")
+        b, s, c = ym.yolo_eval([m[None] for m in maps], ref_yolo["anchors"], nc, np.array(image), **kw)
+    assert np.array_equal(b, ref_yolo["case1_boxes"]) and np.array_equal(s, ref_yolo["case1_scores"])
+    assert np.array_equal(c, ref_yolo["case1_classes"])
+
+
+@live
+def test_live_reference_rejects_what_the_dropin_rejects():
+    """Error behaviour at the boundary: a wrong shape is a ValueError from Model.predict on both sides
+    (the stand-in raises Keras' message; the reference code above it does not catch it)."""
+    with pytest.raises(ValueError):
+        H.run_get_angle(np.zeros((2, 200, 224, 3), np.uint8), {}, lambda x, w: x)
+
+
+# =============================================================================== GPU: the HIP path vs the fixtures
+@pytest.fixture(scope="module")
+def model_f32():
+    import whenet
+    m = whenet.WHENet(dtype="f32")
+    yield m
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", C.SIZES)
+def test_gpu_get_angle_equals_reference_run(model_f32, crops64, ref_angles, n):
+    """north_star: angles within 1e-3 deg of what /root/reference/whenet.py's get_angle returned, argmax identical
+    (outside a 2e-3 logit margin -- the reference-run logits are float32 themselves)."""
+    y, p, r = model_f32.get_angle(crops64[:n])
+    want = ref_angles[f"n{n}_angles"]
+    assert y.dtype == np.float32 and y.shape == (n,) and p.shape == (n,) and r.shape == (n,)
+    if n == 0:
+        return
+    got = np.stack([y, p, r], axis=1)
+    assert np.abs(got - want).max() <= 1e-3, np.abs(got - want).max()
+    lg = ref_angles[f"n{n}_logits"]
+    safe = O.top2_margin(lg) > 2e-3
+    assert safe.mean() > 0.95
+    assert np.array_equal(model_f32.last_argmax[safe], _argmax(lg)[safe])
+    assert np.abs(model_f32.last_logits - lg).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_gpu_real_valued_input_equals_reference_run(model_f32, crops64, ref_angles):
+    y, p, r = model_f32.get_angle(C.real_valued(crops64))
+    assert np.abs(np.stack([y, p, r], axis=1) - ref_angles["real_angles"]).max() <= 1e-3
+    # and through the inner model, the way whenet.py:27 calls it
+    x = C.real_valued(crops64) / 255
+    x = (x - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]
+    outs = model_f32.model.predict(x, batch_size=8)
+    assert [o.shape for o in outs] == [(3, 120), (3, 66), (3, 66)]
+    assert np.abs(np.concatenate(outs, axis=1) - ref_angles["real_logits"]).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_gpu_f16_against_reference_run(crops64, ref_angles):
+    """the throughput configuration against the reference-run angles: inside the f16 contract (DESIGN: <= 1 deg, mean
+    <= 0.12 deg on scene crops), never the 1e-3 bar -- stated, not hidden."""
+    import whenet
+    with whenet.WHENet(dtype="f16") as m:
+        y, p, r = m.get_angle(crops64)
+    err = np.abs(np.stack([y, p, r], axis=1) - ref_angles["n64_angles"])
+    assert err.max() <= 1.0 and err.mean() <= 0.12, (err.max(), err.mean())
+
+
+@pytest.mark.gpu
+def test_gpu_demo_calls_equal_reference_demo_run(model_f32, ref_demo):
+    """what demo.py drew came from get_angle(uint8[1,224,224,3]) on the two Sample/ crops: same call, HIP path."""
+    z = np.load(os.path.join(GOLD, "sample_frames.npz"))
+    for i, call in enumerate(ref_demo["forward_calls"]):
+        y, p, r = model_f32.get_angle(np.expand_dims(z[f"crop{i}"], axis=0))                # demo.py:12-14
+        assert np.abs(np.array([y[0], p[0], r[0]]) - np.array(call[2])).max() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_frame_windows_equal_process_detection(model_f32, ref_rects):
+    """the windows the frame pipeline crops (whenet_submit_frame -> whenet_frame_rects) are the reference-run ones."""
+    from whenet_hip.frames import crop_heads
+    sel = (ref_rects["frame_hw"][:, 0] == 720)
+    boxes, want = ref_rects["boxes"][sel][:64], ref_rects["rects"][sel][:64]
+    frame = synth.video_frame()
+    rects, crops = crop_heads(model_f32, frame, boxes)
+    assert np.array_equal(rects, want)
+    for k in (0, 17, 63):
+        assert np.array_equal(crops[k], P.crop_and_resize(frame, want[k], bgr2rgb=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(C.YOLO_CASES)))
+def test_gpu_yolo_equals_reference_run(model_f32, ref_yolo, i):
+    maps, nc, image, kw = _yolo_case(ref_yolo, i)
+    gb, gs, gc, gi, all_boxes, all_scores = model_f32._handle.yolo_eval(maps, synth.YOLO_ANCHORS, nc, image, debug=True, **kw)
+    assert np.allclose(all_scores, ref_yolo[f"case{i}_all_scores"], rtol=2e-6, atol=1e-7)
+    assert np.allclose(all_boxes, ref_yolo[f"case{i}_all_boxes"], rtol=1e-5, atol=1e-3 * max(image))
+    assert list(gc) == list(ref_yolo[f"case{i}_classes"])
+    assert np.allclose(gs, ref_yolo[f"case{i}_scores"], rtol=2e-6)
+    assert np.allclose(gb, ref_yolo[f"case{i}_boxes"], rtol=1e-5, atol=1e-3 * max(image))
