@@ -25,8 +25,9 @@ __device__ __forceinline__ float swish_f(float x) {
 // here too -- x * v_rcp_f32(1 + v_exp_f32(-x * log2(e))), 5 instructions -- instead of libm's expf and an IEEE division
 // (~25 instructions per value: the f32 fused kernels spent most of their VALU time there).  v_exp_f32 / v_rcp_f32 are 1-ulp
 // operations and the rounded product x * log2(e) moves the result by <= |x| * 4e-8 relative: a few ulp, below the
-// summation noise of the K-deep f32 dot products in front of it (measured: profiles/r04/f32_swish.txt -- the angle error
-// against the float64 oracle is unchanged).  The squeeze-excite gates (sigmoid_f<true>, 1152 values per crop) keep the
+// summation noise of the K-deep f32 dot products in front of it (measured: the f32 error against the float64 oracle on the
+// 512-crop set is unchanged -- 6e-4 deg max before and after, profiles/r04/bench_f32_b64.json `check`, DESIGN/experiments
+// "f32 Swish"; the per-kernel f32 tolerances in tests/test_gpu_parity.py stayed at 2e-5).  The squeeze-excite gates (sigmoid_f<true>, 1152 values per crop) keep the
 // precise forms.  -DWHENET_PRECISE_CONV_SWISH=1 restores round 3's arithmetic.
 #ifndef WHENET_PRECISE_CONV_SWISH
 #define WHENET_PRECISE_CONV_SWISH 0

@@ -233,9 +233,4 @@ int Engine::yolo_eval(const float* const* feats, const int* grid_h, const int* g
     return out;
 }
 
-// Per-launch timing of the forward AS THE TIMED PATH RUNS IT: the same sub-batch chains on the
-// same streams, concurrently, launched eagerly with one HIP event recorded on the chain's stream
-// between consecutive kernels (a launch's time = previous event -> its own event, i.e. kernel plus
-// the boundary in front of it).  Entries: one per launch of a chain; durations averaged over the
-// chains and the iterations; bytes / flops are those of ONE chain's launch (its sub-batch).
 }  // namespace whenet

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(256) void whenet_se_excite_kernel(const float* __re
 template <int RP>
 void launch_ex(const SeExciteArgs& a, hipStream_t stream) {
     const int split = se_excite_split(a.C);
+    // a workgroup gates 256 channels per lane-slot: 1 slot for RP >= 48, 2 otherwise (NCI in the kernel); channels past
+    // that would silently get no gate.  In B0 RP = 48 only occurs with C = 1152 (split 8 -> 144 channels per workgroup).
+    WHENET_REQUIRE((a.C + split - 1) / split <= (RP >= 48 ? 1 : 2) * 256, WHENET_EINVAL,
+                   "se excite: channels per workgroup exceed what the kernel covers");
     hipLaunchKernelGGL(whenet_se_excite_kernel<RP>, dim3(a.n * split), dim3(256), 0, stream, a.rpart, a.np, a.inv_hw,
                        a.b1, a.w2c, a.b2, a.gate, a.C, a.R, split, a.gate_f16);
 }

@@ -118,9 +118,11 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "head_fuse" (0/1, default 1: the head conv (whenet.py:8, last layer) pools its own output, the
  *                  GlobalAveragePooling2D of whenet.py:10, in one kernel (head7.hip; f16, and f32 since round 4b); 0 = conv, then pooling
  *                  inside the heads kernel),
- *          "stem_fuse" (0/1, default 1: f16 handles fed uint8 crops compute the stem conv (whenet.py:8, first layer) inside block 1's
+ *          "stem_fuse" (0/1, default 1: handles of EITHER dtype fed uint8 crops compute the stem conv (whenet.py:8, first layer) inside block 1's
  *                  depthwise kernel (stemdw.hip): the 112 x 112 x 32 stem output never reaches HBM, one launch less; results are
- *                  BITWISE those of the two kernels; 0 = stem.hip, then dw.hip.  The float32-input entry points keep the two),
+ *                  BITWISE those of the two kernels (f16 and f32); 0 = stem.hip, then dw.hip.  The float32-input entry points keep the two.
+ *                  f32 precision note: conv-epilogue Swish uses v_exp_f32 / v_rcp_f32 (1-ulp hardware forms, device_math.h) in both
+ *                  dtypes since round 4; build with -DWHENET_PRECISE_CONV_SWISH=1 for expf + IEEE division),
  *          "fold12" (0/1, default 1: f16 handles whose block 2 runs front2.hip feed that kernel from block 1's depthwise
  *                  output, with block 1's project conv (linear) composed into block 2's expand weights when the
  *                  snapshot is loaded -- one launch and a 112x112x16 round trip through HBM less; 0 = the two convs
@@ -133,9 +135,14 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "inflight" (1..4, default 1: n > 1 gives the handle n engines -- own streams, activation
  *                  arena, graphs, replicated weights -- and spreads whenet_forward_u8_device calls with
  *                  stream == NULL and whenet_submit_* calls over them round-robin, each forward as
- *                  one chain; independent forwards then overlap on the GPU (a forward is a chain of 51
- *                  dependent launches).  The caller gives every forward in flight its own output
+ *                  one chain; independent forwards then overlap on the GPU (a forward is a chain of 46
+ *                  (f16) / 49 (f32) dependent launches: whenet_info_t.n_kernels_per_forward).  The caller gives every forward in flight its own output
  *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
+ *          "min_lane_crops" (>= 1, default 16: the smallest sub-batch a lane may get; "lanes" is cut down until every
+ *                  lane has at least this many crops.  Tests set 1 to force several lanes on small batches),
+ *          "repeat" (1..16, default 1, measurement only: the captured graph holds this many back-to-back copies of
+ *                  the forward, so that one graph launch times `repeat` forwards without the launch boundary
+ *                  between them; results are those of one forward),
  *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
 WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
 

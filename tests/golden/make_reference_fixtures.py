@@ -174,7 +174,7 @@ class OracleHandle:
         pass
 
 
-def run_demo(w):
+def run_demo(w, write=True):
     from whenet_hip import _lib
     tmp = tempfile.mkdtemp(prefix="whenet_demo_")
     weights.save(os.path.join(tmp, "WHENet.h5"), w)                    # demo.py:20 opens 'WHENet.h5' in the cwd
@@ -195,9 +195,10 @@ def run_demo(w):
     rects = [c for c in calls if c[0] == "rectangle"]
     out = {"forward_calls": OracleHandle.calls, "n_lines": len(lines), "rectangles": [list(map(list, r[1:3])) for r in rects],
            "lines": [[list(c[1]), list(c[2]), list(c[3])] for c in lines], "waitKey": [c[1] for c in calls if c[0] == "waitKey"]}
-    with open(os.path.join(HERE, "reference_demo.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    print("demo.py:", json.dumps(out)[:400], flush=True)
+    if write:
+        with open(os.path.join(HERE, "reference_demo.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print("demo.py:", json.dumps(out)[:400], flush=True)
     return out
 
 

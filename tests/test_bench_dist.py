@@ -173,4 +173,6 @@ def test_cgroup_quota_and_measured_parallelism():
     q = bench.cgroup_cpu_quota()
     assert q is None or q > 0
     par = bench.measured_parallelism(2, 0.3)
-    assert par is not None and par["processes"] == 2 and 0.3 < par["by_work"] < 2.6 and par["by_cpu_seconds"] <= 2.2
+    # structural only: a timing ratio on a shared box is not a test oracle (by_work read 3.2 for 2 processes)
+    assert par is not None and par["processes"] == 2
+    assert 0.0 < par["by_work"] <= 2.0 and 0.0 < par["by_cpu_seconds"] <= 2.0

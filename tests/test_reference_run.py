@@ -253,6 +253,20 @@ def test_live_yolo_eval_reproduces_fixture(ref_yolo):
 
 
 @live
+def test_live_demo_main_runs_against_the_dropin_class(weights, ref_demo, capsys):
+    """/root/reference/demo.py's __main__ (:19-30), executed, importing the DROP-IN module as `whenet`: constructor with a
+    positional path, model.model.summary(), get_angle(np.expand_dims(crop, 0)), size-1 arrays into utils.draw_axis.
+    (CPU: the handle behind the class is the float64 oracle; the GPU test feeds the same two crops to the HIP path.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_fixtures", os.path.join(GOLD, "make_reference_fixtures.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    out = gen.run_demo(weights, write=False)
+    assert json.loads(json.dumps(out)) == ref_demo
+    assert "Total params: 4,372,376" in capsys.readouterr().out                      # demo.py:22 printed the summary
+
+
+@live
 def test_live_reference_rejects_what_the_dropin_rejects():
     """Error behaviour at the boundary: a wrong shape is a ValueError from Model.predict on both sides
     (the stand-in raises Keras' message; the reference code above it does not catch it)."""
