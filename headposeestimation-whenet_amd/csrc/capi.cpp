@@ -1,5 +1,6 @@
 // extern "C" surface of libwhenet_hip.so (include/whenet_hip.h).  Every entry point catches
 // everything: no exception crosses the ABI.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -23,6 +24,10 @@ struct whenet_ctx {
     int device_id = 0, dtype = WHENET_F32;
     int inflight = 1;
     size_t next = 0;                                             // round-robin cursor
+    // one large BLOCKING call (whenet_forward_u8 with n >= fanout_min) is cut into fanout_chunk-crop forwards spread over the
+    // engines through their pinned-slot pipelines: copies of chunk i+1 overlap the forward of chunk i, results are bitwise
+    // those of one forward (the kernels are batch-invariant).  fanout_min = 0 switches it off.
+    int fanout_min = 128, fanout_chunk = 64, fanout_stage = 0, fanout_depth = 2;
     std::vector<std::pair<std::string, long>> options;           // replayed on new replicas
     whenet::Engine& at(size_t i) { return i == 0 ? *engine : *replicas[i - 1]; }
     whenet::Engine& take() {
@@ -203,10 +208,27 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
             }
             h->inflight = int(value);
             h->next = 0;
-            // several forwards in flight: each runs as ONE chain, the concurrency comes from the others
+            // several forwards in flight: each runs as ONE chain, the concurrency comes from the others (a blocking host
+            // forward keeps its own chains: Engine::host_lanes_)
             const long lanes = value > 1 ? 1 : 2;
-            e.set_option("lanes", lanes);
-            for (whenet::Engine* r : h->replicas) r->set_option("lanes", lanes);
+            e.set_option("device_lanes", lanes);
+            for (whenet::Engine* r : h->replicas) r->set_option("device_lanes", lanes);
+            return;
+        }
+        if (k == "fanout_min" || k == "fanout_chunk" || k == "fanout_stage" || k == "fanout_depth") {
+            if (k == "fanout_min") {
+                WHENET_REQUIRE(value >= 0, WHENET_EINVAL, "fanout_min must be >= 0 (0 = never)");
+                h->fanout_min = int(std::min<long>(value, 1 << 30));
+            } else if (k == "fanout_chunk") {
+                WHENET_REQUIRE(value >= 1 && value <= 4096, WHENET_EINVAL, "fanout_chunk must be 1..4096");
+                h->fanout_chunk = int(value);
+            } else if (k == "fanout_stage") {
+                WHENET_REQUIRE(value == 0 || value == 1, WHENET_EINVAL, "fanout_stage must be 0 (pinned staging) or 1 (direct)");
+                h->fanout_stage = int(value);
+            } else {
+                WHENET_REQUIRE(value >= 1 && value <= WHENET_MAX_INFLIGHT, WHENET_EINVAL, "fanout_depth must be 1..4");
+                h->fanout_depth = int(value);
+            }
             return;
         }
         e.set_option(k, value);
@@ -216,7 +238,43 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
 }
 
 int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int32_t* argmax, float* logits) {
-    return guarded(h, [&](whenet::Engine& e) { e.forward_host(crops, n, ypr, argmax, logits); });
+    return guarded(h, [&](whenet::Engine& e) {
+        bool pending = e.has_pending();                 // the caller's own submissions hold slots: leave them alone
+        for (whenet::Engine* r : h->replicas) pending = pending || r->has_pending();
+        if (h->fanout_min <= 0 || n < h->fanout_min || n <= h->fanout_chunk || pending) {
+            e.forward_host(crops, n, ypr, argmax, logits);
+            return;
+        }
+        WHENET_REQUIRE(crops != nullptr && ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
+        // get_angle(np.uint8[N,...]) with a large N (whenet.py:22-27 takes any N): chunks round-robin over the engines,
+        // at most fanout_depth outstanding per engine, collected in submission order into the caller's arrays.
+        struct Pending { whenet::Engine* eng; int ticket, off; };
+        std::vector<Pending> q;
+        size_t head = 0;
+        const size_t depth = size_t(h->inflight) * size_t(h->fanout_depth);
+        // one engine: the chunk itself supplies the concurrency (two chains); several engines: one chain each
+        const int lanes = h->inflight > 1 ? 1 : 2;
+        auto collect_one = [&] {
+            const Pending& p = q[head++];
+            const size_t o = size_t(p.off);
+            p.eng->collect(p.ticket, ypr + o * 3, argmax ? argmax + o * 3 : nullptr, logits ? logits + o * 252 : nullptr);
+        };
+        try {
+            size_t eng_i = 0;
+            for (int off = 0; off < n; off += h->fanout_chunk) {
+                if (q.size() - head >= depth) collect_one();
+                const int cnt = std::min(h->fanout_chunk, n - off);
+                whenet::Engine& eng = h->at(eng_i);
+                eng_i = (eng_i + 1) % size_t(h->inflight);
+                q.push_back(Pending{&eng, eng.submit(crops + size_t(off) * 150528, cnt, h->fanout_stage, lanes), off});
+            }
+            while (head < q.size()) collect_one();
+        } catch (...) {
+            e.abandon_submissions();
+            for (whenet::Engine* r : h->replicas) r->abandon_submissions();
+            throw;
+        }
+    });
 }
 
 int whenet_forward_f32(whenet_t* h, const float* image, int n, float* ypr, int32_t* argmax, float* logits) {

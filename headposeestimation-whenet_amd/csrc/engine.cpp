@@ -218,9 +218,12 @@ void Engine::set_option(const std::string& key, long value) {
         drop_graphs();
     } else if (key == "poison") {
         poison_ = value != 0;
-    } else if (key == "lanes") {
+    } else if (key == "lanes" || key == "device_lanes") {
+        // "lanes": every forward; "device_lanes" (set by the handle's "inflight" option): the asynchronous device-side
+        // entry points only -- a blocking host forward keeps host_lanes_
         WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "lanes must be 1..8");
         lanes_ = int(value);
+        if (key == "lanes") host_lanes_ = int(value);
         sync();
         drop_graphs();
     } else if (key == "split_heads") {
@@ -231,6 +234,9 @@ void Engine::set_option(const std::string& key, long value) {
         lane_graphs_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "host_lanes") {
+        WHENET_REQUIRE(value >= 1 && value <= MAX_LANES, WHENET_EINVAL, "host_lanes must be 1..8");
+        host_lanes_ = int(value);
     } else if (key == "min_lane_crops") {
         WHENET_REQUIRE(value >= 1, WHENET_EINVAL, "min_lane_crops must be >= 1");
         min_lane_crops_ = int(value);
@@ -375,7 +381,7 @@ struct Rec {
 // reads it: block 2 has no skip).
 // Which kernels a block runs (options fuse_front / front_impl / se_fuse / pw_impl and the per-layer tables): ONE statement of
 // it, used by enqueue_block() and by get_info()'s launch count.
-Engine::BlockSchedule Engine::block_schedule(const DevBlock& b) const {
+Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
     BlockSchedule r;
     r.fused = fuse_front_ && b.spec.has_expand() && pw_impl_ == 0;
     r.use_f7 = r.fused && front_impl_ == 1 && front7_ && b.f7_supported;
@@ -384,7 +390,10 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b) const {
     r.se_ntiles = r.use_f7 ? 1 : (r.use_f2 ? b.f2plan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles()));
     r.se_chunks = r.use_f7 ? b.f7_chunks : (r.use_f2 ? b.f2plan.chunks : b.fplan.chunks);
     const bool se_pays = b.project.K < 320 && r.se_ntiles * r.se_chunks <= 24;
-    r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && se_pays));
+    // a chain of <= 4 crops is launch-bound (DESIGN: B=1 = 46 launches x ~6 us): there every launch saved pays, whatever the
+    // prologue costs per workgroup (measured +3 % at B=1 with se_fuse=2).  Same bits either way.
+    const bool tiny = !single_stage_call_ && n > 0 && n <= SE_FUSE_ALWAYS_MAX_CROPS;
+    r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && (se_pays || tiny)));
     return r;
 }
 
@@ -422,7 +431,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const int hw_in = sp.h_in * sp.h_in, hw_out = sp.h_out * sp.h_out;
     const int cexp = sp.cexp();
     const void* dw_in = in;
-    const BlockSchedule bs = block_schedule(b);
+    const BlockSchedule bs = block_schedule(b, n);
     const bool fused = bs.fused, use_f2 = bs.use_f2, se_in_front = bs.se_in_front, se_fused = bs.se_fused;
     const int se_ntiles = bs.se_ntiles, se_chunks = bs.se_chunks;
     // (checked before anything is enqueued: a violated invariant must not leave half a block in a stream capture)
@@ -763,9 +772,14 @@ Engine::View Engine::view(int crop_off) const {
 // parallel branches of ONE graph).  Crops are independent, so the split changes nothing in the
 // results; what it buys is overlap: most kernels of this network are short (10-30 us) and
 // latency-bound, and two chains in flight fill each other's launch / drain bubbles.
-void Engine::enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
-    int lanes = lanes_;
+int Engine::lanes_for(int n, int want) const {
+    int lanes = want > 0 ? std::min(want, MAX_LANES) : lanes_;
     while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
+    return lanes;
+}
+
+void Engine::enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s, int want) {
+    const int lanes = lanes_for(n, want);
     if (lanes <= 1) {
         enqueue_forward(view(0), d_in, n, d_ypr, d_amax, d_logits, s, nullptr);
         return;
@@ -815,7 +829,7 @@ hipGraphExec_t Engine::cached_graph(const GraphKey& key, hipStream_t s, F&& fn) 
     return exec;
 }
 
-void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s) {
+void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s, int want) {
     if (poison_) {
         // debug option "poison": every activation buffer holds NaN bit patterns when the forward starts, so a kernel
         // that reads what no kernel of THIS forward wrote shows up in the results (tests/test_gpu_parity.py)
@@ -829,11 +843,10 @@ void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_am
         WHENET_HIP_CHECK(hipMemsetAsync(gate_, 0xff, N * 1152 * sizeof(float), s));
     }
     if (!use_graph_) {
-        enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s);
+        enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s, want);
         return;
     }
-    int lanes = lanes_;
-    while (lanes > 1 && n / lanes < min_lane_crops_) --lanes;
+    const int lanes = lanes_for(n, want);
     if (lanes > 1) (void)lane_stream(lanes - 2);        // the lane streams exist before any capture starts
     if (lane_graphs_ && lanes > 1) {
         // One graph PER LANE, each launched on its own stream: the chains then run as independent queues.
@@ -860,8 +873,8 @@ void Engine::run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_am
         }
         return;
     }
-    hipGraphExec_t g = cached_graph(GraphKey{n, -1, d_in, d_ypr, d_amax, d_logits}, s,
-                                    [&] { enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s); });
+    hipGraphExec_t g = cached_graph(GraphKey{n, -lanes, d_in, d_ypr, d_amax, d_logits}, s,
+                                    [&] { enqueue_lanes(d_in, n, d_ypr, d_amax, d_logits, s, lanes); });
     WHENET_HIP_CHECK(hipGraphLaunch(g, s));
 }
 
@@ -888,7 +901,8 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
     //  second lane's crops travel, changes nothing -- 68.5 k vs 69.6 k crops/s at 64 crops: the 9.6 MB copy from pageable
     //  memory is 0.18 ms of a 0.92 ms call, and two graphs on two streams lose what the overlap gains.)
     WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
-    run_forward(in_u8_, n, o_ypr_, o_amax_, o_logits_, stream_);
+    // a blocking call has the GPU to itself whatever "inflight" says: the forward runs as host_lanes_ chains
+    run_forward(in_u8_, n, o_ypr_, o_amax_, o_logits_, stream_, host_lanes_);
     WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     if (logits)
@@ -964,7 +978,7 @@ void Engine::ensure_slot(Slot& s, int n) {
     s.capacity = n;
 }
 
-int Engine::submit(const uint8_t* crops, int n) {
+int Engine::submit(const uint8_t* crops, int n, int stage, int want_lanes) {
     DeviceGuard guard(device_);
     require_model();
     WHENET_REQUIRE(crops != nullptr, WHENET_EINVAL, "crops must not be NULL");
@@ -981,11 +995,17 @@ int Engine::submit(const uint8_t* crops, int n) {
     // Through a pinned slot: a copy straight from the caller's pageable memory (hipMemcpyAsync stages it inside the runtime)
     // blocks the host until the DMA is done and serialises the submissions -- measured round 4: 67.8 k vs 90.4 k crops/s with
     // three 64-crop batches in flight.
-    std::memcpy(slot->h_in, crops, N * IN_BYTES);
-    WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream()));
+    // stage 1 (the fan-out of one large blocking call, capi.cpp): straight from the caller's memory on the copy stream -- the
+    // host blocks for THIS chunk's DMA only, while the forwards of the chunks before it run.
+    if (stage == 1) {
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, crops, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream()));
+    } else {
+        std::memcpy(slot->h_in, crops, N * IN_BYTES);
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream()));
+    }
     WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream()));
     WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
-    run_forward(slot->d_in, n, slot->d_ypr, slot->d_amax, slot->d_logits, stream_);
+    run_forward(slot->d_in, n, slot->d_ypr, slot->d_amax, slot->d_logits, stream_, want_lanes);
     WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_ypr, slot->d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_amax, slot->d_amax, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_logits, slot->d_logits, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
@@ -994,6 +1014,14 @@ int Engine::submit(const uint8_t* crops, int n) {
     slot->n = n;
     slot->ticket = next_ticket_++;
     return slot->ticket;
+}
+
+// After a failed fan-out: wait for whatever was enqueued and hand every slot back.
+void Engine::abandon_submissions() {
+    DeviceGuard guard(device_);
+    (void)hipStreamSynchronize(stream_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    for (Slot& s : slots_) s.busy = false;
 }
 
 void Engine::collect(int ticket, float* ypr, int32_t* argmax, float* logits) {

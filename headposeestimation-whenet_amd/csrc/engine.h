@@ -80,7 +80,13 @@ class Engine {
                         hipStream_t stream);
     void sync();
     void release_aux_streams();
-    int submit(const uint8_t* crops, int n);
+    int submit(const uint8_t* crops, int n, int stage = 0, int want_lanes = 0);
+    void abandon_submissions();
+    bool has_pending() const {
+        for (const Slot& s : slots_)
+            if (s.busy) return true;
+        return false;
+    }
     int submit_frame(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k);
     void op_crop_resize(const uint8_t* frame, int fh, int fw, int swap_rb, const int32_t* rects, int k,
                         uint8_t* crops_out);
@@ -151,12 +157,16 @@ class Engine {
         bool fused = false, use_f2 = false, use_f7 = false, se_in_front = false, se_fused = false;
         int se_ntiles = 1, se_chunks = 1;
     };
-    BlockSchedule block_schedule(const DevBlock& b) const;
-    void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
-    void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s);
+    // n = crops of the chain the block runs in (0: not batch-specific, e.g. the launch count of get_info)
+    BlockSchedule block_schedule(const DevBlock& b, int n = 0) const;
+    static constexpr int SE_FUSE_ALWAYS_MAX_CROPS = 4;
+    bool single_stage_call_ = false;   // op_block / op_block_range: the schedule must not depend on the test's batch size
+    int lanes_for(int n, int want) const;     // chains a forward of n crops runs as (want = 0: option "lanes")
+    void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s, int want = 0);
+    void run_forward(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s, int want = 0);
     void ensure_slot(Slot& s, int n);
     hipStream_t lane_stream(int i);     // created on first use
-    using GraphKey = std::tuple<int, int, const void*, void*, void*, void*>;   // n, lane offset (-1: whole batch), buffers
+    using GraphKey = std::tuple<int, int, const void*, void*, void*, void*>;   // n, lane offset (-L: whole batch as L chains), buffers
     template <typename F>
     hipGraphExec_t cached_graph(const GraphKey& key, hipStream_t s, F&& fn);
     void sync_streams(hipStream_t s);
@@ -188,6 +198,7 @@ class Engine {
                                 // equal from 256 crops up and for f32)
     bool lane_graphs_ = false;  // one graph per lane on its own stream instead of one forked graph (option "lane_graphs")
     int min_lane_crops_ = 16;   // do not split below this many crops per chain
+    int host_lanes_ = 2;        // chains of a BLOCKING host forward (it has the GPU to itself whatever "inflight" says)
     std::vector<hipStream_t> lane_streams_;
     std::vector<hipEvent_t> join_ev_;
     hipEvent_t fork_ev_ = nullptr;

@@ -40,7 +40,14 @@ void Engine::op_block(int index, const float* in, int n, float* expand_out, floa
     WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
     launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
     WHENET_HIP_CHECK(hipMemsetAsync(gate_, 0xff, N * 1152 * sizeof(float), stream_));     // (NaN unless a launch writes it)
-    enqueue_block(b, view(0), x0_, x1_, n, stream_, nullptr);
+    single_stage_call_ = true;
+    try {
+        enqueue_block(b, view(0), x0_, x1_, n, stream_, nullptr);
+    } catch (...) {
+        single_stage_call_ = false;
+        throw;
+    }
+    single_stage_call_ = false;
     auto fetch = [&](const void* src, size_t elems, float* dst) {
         if (!dst) return;
         launch_act_to_f32(src, d_f32, elems, dtype_, stream_);
@@ -72,7 +79,15 @@ void Engine::op_block_range(int first, int last, const float* in, int n, float* 
     WHENET_HIP_CHECK(hipMemcpyAsync(d_f32, in, in_elems * sizeof(float), hipMemcpyHostToDevice, stream_));
     launch_f32_to_act(d_f32, x0_, in_elems, dtype_, stream_);
     const View v = view(0);
-    const void* res = enqueue_blocks(first, last, v, v.x0, n, stream_, nullptr);
+    single_stage_call_ = true;
+    const void* res = nullptr;
+    try {
+        res = enqueue_blocks(first, last, v, v.x0, n, stream_, nullptr);
+    } catch (...) {
+        single_stage_call_ = false;
+        throw;
+    }
+    single_stage_call_ = false;
     launch_act_to_f32(res, d_f32, out_elems, dtype_, stream_);
     WHENET_HIP_CHECK(hipMemcpyAsync(out, d_f32, out_elems * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));

@@ -15,7 +15,11 @@ and an MI355X the constructor raises.
 
 Extras that the reference does not have (keyword-only, all optional):
   device=0            GPU ordinal
+  devices=[0,1,..]    several GPUs from this one process: one handle + feeder thread per device, the batch of each
+                      get_angle call split contiguously over them (whenet_hip/multi.py), same bits
   dtype='f32'|'f16'   activation / 1x1-weight type (f32 = parity configuration)
+  inflight=1..4       engines per handle that one large get_angle call (N >= 128) is spread over in 64-crop chunks, copies
+                      overlapping forwards (include/whenet_hip.h "fanout_min"); default: 3, created at the first such call
   .predict            alias of get_angle (BASELINE.json words the API as WHENet.predict(crop))
   .last_logits, .last_argmax   what Model.predict returned for the last call, and the bin argmax
 """
@@ -99,7 +103,7 @@ class _Model:
 
 
 class WHENet:
-    def __init__(self, snapshot=None, *, device=0, dtype="f32"):
+    def __init__(self, snapshot=None, *, device=0, dtype="f32", devices=None, inflight=None):
         if isinstance(dtype, str):
             if dtype.lower() not in _DTYPES:
                 raise ValueError(f"dtype must be one of {sorted(set(_DTYPES))}")
@@ -117,7 +121,17 @@ class WHENet:
                 snapshot = keras_h5.load_as_packed(path)          # Keras HDF5 -> WHNPACK1 bytes
             else:
                 snapshot = path
-        self._handle = _lib.Handle(snapshot, device=int(device), dtype=dtype)
+        if inflight is not None and not (1 <= int(inflight) <= 4):
+            raise ValueError("inflight must be 1..4")
+        if devices is not None:
+            from whenet_hip.multi import MultiDeviceHandle
+            self._handle = MultiDeviceHandle(snapshot, [int(d) for d in devices], dtype)
+        else:
+            self._handle = _lib.Handle(snapshot, device=int(device), dtype=dtype)
+        self._inflight = None if inflight is None else int(inflight)
+        self._fanout_ready = False
+        if self._inflight is not None:
+            self._prepare_fanout()
         self.model = _Model(self)
         self.idx_tensor = [idx for idx in range(66)]                       # whenet.py:17-20
         self.idx_tensor = np.array(self.idx_tensor, dtype=np.float32)
@@ -126,7 +140,16 @@ class WHENet:
         self.last_logits = None
         self.last_argmax = None
 
+    FANOUT_MIN = 128          # include/whenet_hip.h "fanout_min"
+
+    def _prepare_fanout(self):
+        """Replica engines for the chunked fan-out of large batches (one-off: weights + a 64-crop arena per engine)."""
+        self._handle.set_option("inflight", 3 if self._inflight is None else self._inflight)
+        self._fanout_ready = True
+
     def _forward(self, u8: np.ndarray):
+        if not self._fanout_ready and u8.shape[0] >= self.FANOUT_MIN:
+            self._prepare_fanout()
         ypr, am, lg = self._handle.forward(u8, want_logits=True)
         self.last_logits, self.last_argmax = lg, am
         return ypr, am, lg

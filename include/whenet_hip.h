@@ -138,6 +138,13 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  one chain; independent forwards then overlap on the GPU (a forward is a chain of 46
  *                  (f16) / 49 (f32) dependent launches: whenet_info_t.n_kernels_per_forward).  The caller gives every forward in flight its own output
  *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
+ *          "fanout_min" (>= 0, default 128: a blocking whenet_forward_u8 of at least this many crops is cut into
+ *                  "fanout_chunk"-crop forwards (default 64) that travel through the handle's pinned submission slots,
+ *                  round-robin over its "inflight" engines, at most "fanout_depth" (1..4, default 2) outstanding per engine:
+ *                  the copy of chunk i+1 overlaps the forward of chunk i.  Results are bitwise those of one forward.
+ *                  0 = never.  "fanout_stage": 0 = chunks are copied into pinned staging first (default), 1 = DMA straight
+ *                  from the caller's memory),
+ *          "host_lanes" (1..8, default 2: chains a BLOCKING host forward runs as; "lanes" sets both),
  *          "min_lane_crops" (>= 1, default 16: the smallest sub-batch a lane may get; "lanes" is cut down until every
  *                  lane has at least this many crops.  Tests set 1 to force several lanes on small batches),
  *          "repeat" (1..16, default 1, measurement only: the captured graph holds this many back-to-back copies of
