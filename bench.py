@@ -344,6 +344,37 @@ def host_leg(h, crops):
             "note": "host uint8 crops in, angles out; H2D 9.6 MB per batch of 64 over PCIe included"}
 
 
+def dropin_leg(blob, device):
+    """The reference's own call shapes through the drop-in CLASS (python, ctypes, PCIe, everything included):
+    get_angle(uint8[1,224,224,3]) per head (demo.py:14, demo_video.py:27) as wall-clock latency, f32 (the parity
+    configuration) and f16; get_angle(uint8[512,...]) as host->host throughput (whenet.py:22-27 takes any N; large
+    batches are cut into chunks over the handle's engines, include/whenet_hip.h "fanout_min")."""
+    import whenet
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 256, (512, 224, 224, 3), dtype=np.uint8)
+    out = {}
+    for dd in ("f32", "f16"):
+        with whenet.WHENet(snapshot=blob, dtype=dd, device=device) as m:
+            one = big[:1]
+            lat = []
+            for _ in range(700):
+                a = time.perf_counter()
+                m.get_angle(one)
+                lat.append(time.perf_counter() - a)
+            lat = np.array(lat[100:]) * 1e6
+            out[f"get_angle_b1_{dd}"] = {"median_us": float(np.median(lat)), "p99_us": float(np.percentile(lat, 99)), "iters": 600}
+            for _ in range(3):
+                m.get_angle(big)
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < (0.8 if dd == "f16" else 0.5):
+                m.get_angle(big)
+                k += 1
+            out[f"get_angle_b512_{dd}_crops_s"] = k * 512 / (time.perf_counter() - t0)
+    out["note"] = "whenet.WHENet(...).get_angle(numpy uint8): python + ctypes + H2D + forward + D2H, pageable host memory"
+    return out
+
+
 def yolo_leg(h):
     """yolo_eval (yolo_v3/model.py:193-232) for one 416x416 detector output (10,647 boxes, one
     class), host maps in -> detections out (H2D of 255 KB included), next to the numpy restatement on the host."""
@@ -817,6 +848,8 @@ def main():
         out["frame_pipeline"] = frame_leg(h)
         # PCIe-inclusive rates of the host-pointer forms on the same batch (never `value`)
         out["pcie_inclusive"] = host_leg(h, crops)
+        # the drop-in class on the reference's call shapes (B=1 wall latency; one 512-crop call), never `value`
+        out["dropin"] = dropin_leg(blob, local_rank)
         out["yolo_postprocess"] = yolo_leg(h)
     if rank == 0 and world == 1 and not distributed and not args.no_sweep and args.dtype == "f16" and B == 64 and not args.strong:
         out["sweep"] = sweep_leg(blob, local_rank, dev, args.lanes)

@@ -149,7 +149,7 @@ Engine::~Engine() {
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     for (auto& kv : graphs_) (void)hipGraphExecDestroy(kv.second);
     graphs_.clear();
-    for (Slot& s : slots_) {
+    auto free_slot_buffers = [](Slot& s) {
         if (s.h_in) (void)hipHostFree(s.h_in);
         if (s.h_ypr) (void)hipHostFree(s.h_ypr);
         if (s.h_amax) (void)hipHostFree(s.h_amax);
@@ -164,7 +164,9 @@ Engine::~Engine() {
         if (s.d_plan) (void)hipFree(s.d_plan);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.done) (void)hipEventDestroy(s.done);
-    }
+    };
+    for (Slot& s : slots_) free_slot_buffers(s);
+    free_slot_buffers(host_slot_);
     void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, hcount_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_, yolo_scratch_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
@@ -232,6 +234,15 @@ void Engine::set_option(const std::string& key, long value) {
         drop_graphs();
     } else if (key == "lane_graphs") {
         lane_graphs_ = value != 0;
+        sync();
+        drop_graphs();
+    } else if (key == "host_pinned_max") {
+        WHENET_REQUIRE(value >= 0 && value <= 4096, WHENET_EINVAL, "host_pinned_max must be 0..4096");
+        sync();
+        host_pinned_max_ = int(value);
+    } else if (key == "se_fuse_tiny") {
+        WHENET_REQUIRE(value >= 0 && value <= 64, WHENET_EINVAL, "se_fuse_tiny must be 0..64");
+        se_fuse_tiny_ = int(value);
         sync();
         drop_graphs();
     } else if (key == "host_lanes") {
@@ -390,9 +401,10 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
     r.se_ntiles = r.use_f7 ? 1 : (r.use_f2 ? b.f2plan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles()));
     r.se_chunks = r.use_f7 ? b.f7_chunks : (r.use_f2 ? b.f2plan.chunks : b.fplan.chunks);
     const bool se_pays = b.project.K < 320 && r.se_ntiles * r.se_chunks <= 24;
-    // a chain of <= 4 crops is launch-bound (DESIGN: B=1 = 46 launches x ~6 us): there every launch saved pays, whatever the
-    // prologue costs per workgroup (measured +3 % at B=1 with se_fuse=2).  Same bits either way.
-    const bool tiny = !single_stage_call_ && n > 0 && n <= SE_FUSE_ALWAYS_MAX_CROPS;
+    // option "se_fuse_tiny" (default 0 = off): chains of at most that many crops fuse every block's gate.  Round 4 read +3 % at
+    // B=1 for se_fuse=2 on device-resident input; round 5 measured the host call (get_angle(uint8[1,...])) the other way
+    // round -- 490 us fused against 461 us with the 13 excite launches (f32), 379 against 353 (f16) -- so it stays off.
+    const bool tiny = !single_stage_call_ && n > 0 && n <= se_fuse_tiny_;
     r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && (se_pays || tiny)));
     return r;
 }
@@ -897,6 +909,26 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
     WHENET_REQUIRE(crops != nullptr && ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
     ensure_capacity(n);
     const size_t N = size_t(n);
+    if (n <= host_pinned_max_) {
+        // The reference's own call shape -- get_angle(uint8[1,224,224,3]) per head (demo.py:14, demo_video.py:27): latency.
+        // Copies to and from PAGEABLE memory are synchronous inside the runtime (the three result copies each wait for the
+        // forward and go through its staging buffer one after the other); through a pinned slot the call is memcpy ->
+        // H2D -> graph -> 3 D2H, all asynchronous on ONE stream, one wait, memcpy out (round 5: 490 -> see DESIGN us at B=1 f32).
+        Slot& sl = host_slot_;
+        ensure_slot(sl, std::max(n, std::min(host_pinned_max_, 16)));
+        std::memcpy(sl.h_in, crops, N * IN_BYTES);
+        WHENET_HIP_CHECK(hipMemcpyAsync(sl.d_in, sl.h_in, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
+        run_forward(sl.d_in, n, sl.d_ypr, sl.d_amax, sl.d_logits, stream_, host_lanes_);
+        WHENET_HIP_CHECK(hipMemcpyAsync(sl.h_ypr, sl.d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(sl.h_amax, sl.d_amax, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+        if (logits)
+            WHENET_HIP_CHECK(hipMemcpyAsync(sl.h_logits, sl.d_logits, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+        std::memcpy(ypr, sl.h_ypr, N * 3 * sizeof(float));
+        if (argmax) std::memcpy(argmax, sl.h_amax, N * 3 * sizeof(int32_t));
+        if (logits) std::memcpy(logits, sl.h_logits, N * N_LOGITS * sizeof(float));
+        return;
+    }
     // (Measured, round 4: issuing the copy lane by lane in front of per-lane graphs, so that the first chain runs while the
     //  second lane's crops travel, changes nothing -- 68.5 k vs 69.6 k crops/s at 64 crops: the 9.6 MB copy from pageable
     //  memory is 0.18 ms of a 0.92 ms call, and two graphs on two streams lose what the overlap gains.)

@@ -159,7 +159,7 @@ class Engine {
     };
     // n = crops of the chain the block runs in (0: not batch-specific, e.g. the launch count of get_info)
     BlockSchedule block_schedule(const DevBlock& b, int n = 0) const;
-    static constexpr int SE_FUSE_ALWAYS_MAX_CROPS = 4;
+    int se_fuse_tiny_ = 0;             // option "se_fuse_tiny"
     bool single_stage_call_ = false;   // op_block / op_block_range: the schedule must not depend on the test's batch size
     int lanes_for(int n, int want) const;     // chains a forward of n crops runs as (want = 0: option "lanes")
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s, int want = 0);
@@ -237,6 +237,8 @@ class Engine {
     std::map<GraphKey, hipGraphExec_t> graphs_;
 
     Slot slots_[WHENET_MAX_INFLIGHT];
+    Slot host_slot_;                   // pinned staging of small BLOCKING host forwards (forward_host, n <= host_pinned_max_)
+    int host_pinned_max_ = 32;
     int next_ticket_ = 0;
 };
 

@@ -18,8 +18,8 @@ Extras that the reference does not have (keyword-only, all optional):
   devices=[0,1,..]    several GPUs from this one process: one handle + feeder thread per device, the batch of each
                       get_angle call split contiguously over them (whenet_hip/multi.py), same bits
   dtype='f32'|'f16'   activation / 1x1-weight type (f32 = parity configuration)
-  inflight=1..4       engines per handle that one large get_angle call (N >= 128) is spread over in 64-crop chunks, copies
-                      overlapping forwards (include/whenet_hip.h "fanout_min"); default: 3, created at the first such call
+  inflight=1..4       engines per handle that one large get_angle call (N >= 256) is spread over in 128-crop chunks, copies
+                      overlapping forwards (include/whenet_hip.h "fanout_min"); default: 2, created at the first such call
   .predict            alias of get_angle (BASELINE.json words the API as WHENet.predict(crop))
   .last_logits, .last_argmax   what Model.predict returned for the last call, and the bin argmax
 """
@@ -140,11 +140,11 @@ class WHENet:
         self.last_logits = None
         self.last_argmax = None
 
-    FANOUT_MIN = 128          # include/whenet_hip.h "fanout_min"
+    FANOUT_MIN = 256          # include/whenet_hip.h "fanout_min"
 
     def _prepare_fanout(self):
         """Replica engines for the chunked fan-out of large batches (one-off: weights + a 64-crop arena per engine)."""
-        self._handle.set_option("inflight", 3 if self._inflight is None else self._inflight)
+        self._handle.set_option("inflight", 2 if self._inflight is None else self._inflight)
         self._fanout_ready = True
 
     def _forward(self, u8: np.ndarray):

@@ -138,12 +138,17 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  one chain; independent forwards then overlap on the GPU (a forward is a chain of 46
  *                  (f16) / 49 (f32) dependent launches: whenet_info_t.n_kernels_per_forward).  The caller gives every forward in flight its own output
  *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
- *          "fanout_min" (>= 0, default 128: a blocking whenet_forward_u8 of at least this many crops is cut into
- *                  "fanout_chunk"-crop forwards (default 64) that travel through the handle's pinned submission slots,
+ *          "fanout_min" (>= 0, default 256: a blocking whenet_forward_u8 of at least this many crops is cut into
+ *                  "fanout_chunk"-crop forwards (default 128) that travel through the handle's pinned submission slots,
  *                  round-robin over its "inflight" engines, at most "fanout_depth" (1..4, default 2) outstanding per engine:
  *                  the copy of chunk i+1 overlaps the forward of chunk i.  Results are bitwise those of one forward.
- *                  0 = never.  "fanout_stage": 0 = chunks are copied into pinned staging first (default), 1 = DMA straight
- *                  from the caller's memory),
+ *                  0 = never.  "fanout_stage": 0 = chunks are copied into pinned staging first, 1 = DMA straight from the
+ *                  caller's memory (default; measured round 5 with 2 engines: 126 k against 109 k crops/s at N = 512)),
+ *          "host_pinned_max" (0..4096, default 32: a blocking whenet_forward_u8 of at most this many crops travels through a
+ *                  pinned staging slot -- one asynchronous H2D, the forward, three asynchronous D2H, ONE wait -- instead of
+ *                  four synchronous copies from / to the caller's pageable memory: the latency path of the reference's
+ *                  per-head call shape (demo.py:14, demo_video.py:27)),
+ *          "se_fuse_tiny" (0..64, default 0: chains of at most this many crops behave as se_fuse = 2),
  *          "host_lanes" (1..8, default 2: chains a BLOCKING host forward runs as; "lanes" sets both),
  *          "min_lane_crops" (>= 1, default 16: the smallest sub-batch a lane may get; "lanes" is cut down until every
  *                  lane has at least this many crops.  Tests set 1 to force several lanes on small batches),

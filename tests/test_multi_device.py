@@ -119,9 +119,9 @@ def test_min_shard_keeps_small_batches_on_one_device(fake):
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_gpu_two_handles_on_one_device_are_bitwise_one_handle(dtype):
     import whenet
-    crops = np.concatenate([synth.scene_crops(100, seed=5), synth.noise_crops(37, seed=6)])       # 137: ragged, >= fan-out
+    crops = np.concatenate([synth.scene_crops(200, seed=5), synth.noise_crops(77, seed=6)])       # 277: ragged, >= fan-out
     with whenet.WHENet(dtype=dtype) as one, whenet.WHENet(dtype=dtype, devices=[0, 0]) as two:
-        for n in (1, 2, 7, 64, 137):
+        for n in (1, 2, 7, 64, 277):
             a = one.get_angle(crops[:n])
             la, aa = one.last_logits.copy(), one.last_argmax.copy()
             b = two.get_angle(crops[:n])
@@ -136,7 +136,7 @@ def test_gpu_two_handles_on_one_device_are_bitwise_one_handle(dtype):
 
 @pytest.mark.gpu
 def test_gpu_large_batch_fanout_is_bitwise_one_forward():
-    """get_angle(np.uint8[N >= 128]) is cut into 64-crop forwards over the handle's engines (capi.cpp, option fanout_min):
+    """get_angle(np.uint8[N >= 256]) is cut into 128-crop forwards over the handle's engines (capi.cpp, option fanout_min):
     same bits as the single forward, ragged tail, every staging mode / depth / chunk size; errors leave the handle usable."""
     crops = np.concatenate([synth.scene_crops(200, seed=15), synth.noise_crops(77, seed=16)])      # 277
     from whenet_hip import weights as W
