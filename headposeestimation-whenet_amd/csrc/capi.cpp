@@ -27,7 +27,7 @@ struct whenet_ctx {
     // one large BLOCKING call (whenet_forward_u8 with n >= fanout_min) is cut into fanout_chunk-crop forwards spread over the
     // engines through their pinned-slot pipelines: copies of chunk i+1 overlap the forward of chunk i, results are bitwise
     // those of one forward (the kernels are batch-invariant).  fanout_min = 0 switches it off.
-    int fanout_min = 256, fanout_chunk = 128, fanout_stage = 1, fanout_depth = 2;
+    int fanout_min = 256, fanout_chunk = 64, fanout_stage = 1, fanout_depth = 2;
     std::vector<std::pair<std::string, long>> options;           // replayed on new replicas
     whenet::Engine& at(size_t i) { return i == 0 ? *engine : *replicas[i - 1]; }
     whenet::Engine& take() {

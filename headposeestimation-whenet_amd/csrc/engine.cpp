@@ -31,15 +31,21 @@ DevPw Engine::upload_pw(const HostPw& h) {
     d.KS = h.KS;
     d.NTILES = h.NTILES;
     d.wp = upload_bytes(h.packed.data(), h.packed.size());
+    if (!h.packed_split.empty()) {
+        d.wps = upload_bytes(h.packed_split.data(), h.packed_split.size());
+        d.KSs = h.KS_split;
+        d.wsi = h.wsi;
+    }
     d.wdense = upload(h.dense);
     d.bias = upload(h.bias);
     return d;
 }
 
-Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype) : device_(device_id), dtype_(dtype) {
+Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype)
+    : device_(device_id), dtype_(dtype == WHENET_F32S ? WHENET_F32 : dtype), split_(dtype == WHENET_F32S) {
     // host-side preparation first: a malformed snapshot is reported as such even on a box
     // without a GPU
-    HostModel m = build_host_model(parse_snapshot(snapshot, nbytes), dtype);
+    HostModel m = build_host_model(parse_snapshot(snapshot, nbytes), dtype_, split_);
     params_backbone_ = m.params_backbone;
     params_heads_ = m.params_heads;
     n_tensors_ = m.n_tensors;
@@ -234,6 +240,11 @@ void Engine::set_option(const std::string& key, long value) {
         drop_graphs();
     } else if (key == "lane_graphs") {
         lane_graphs_ = value != 0;
+        sync();
+        drop_graphs();
+    } else if (key == "split_pw") {
+        WHENET_REQUIRE(split_ || value == 0, WHENET_EINVAL, "split_pw: the handle was not created as WHENET_F32S");
+        split_pw_ = value != 0;
         sync();
         drop_graphs();
     } else if (key == "host_pinned_max") {
@@ -541,6 +552,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.N = b.expand.N;
         a.KS = b.expand.KS;
         a.NTILES = b.expand.NTILES;
+        set_split(a, b.expand);
         a.HW = hw_in;
         a.act = ACT_SWISH;
         R(p + "/expand", "pw", kernel_name_pw(a, dtype_, pw_impl_, num_cus_).c_str(), double(a.M) * (a.K + a.N) * es,
@@ -633,6 +645,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.N = b.project.N;
         a.KS = b.project.KS;
         a.NTILES = b.project.NTILES;
+        set_split(a, b.project);
         a.HW = hw_out;
         a.act = ACT_NONE;
         R(p + "/project", "pw", kernel_name_pw(a, dtype_, pw_impl_, num_cus_).c_str(),
@@ -711,6 +724,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.N = head_.N;
         a.KS = head_.KS;
         a.NTILES = head_.NTILES;
+        set_split(a, head_);
         a.HW = 49;
         a.act = ACT_SWISH;
         R("head", "pw", kernel_name_pw(a, dtype_, pw_impl_, num_cus_).c_str(), double(a.M) * (a.K + a.N) * es,

@@ -18,6 +18,9 @@ namespace whenet {
 struct DevPw {
     int K = 0, N = 0, KS = 0, NTILES = 0;
     void* wp = nullptr;
+    void* wps = nullptr;       // WHENET_F32S: split weight images (HostPw::packed_split)
+    int KSs = 0;
+    float wsi = 1.0f;
     float* wdense = nullptr;
     float* bias = nullptr;
 };
@@ -65,7 +68,7 @@ constexpr int MAX_LANES = 8;
 
 class Engine {
   public:
-    Engine(const void* snapshot, size_t nbytes, int device_id, int dtype);
+    Engine(const void* snapshot, size_t nbytes, int device_id, int dtype);      // dtype: WHENET_F32 / F16 / F32S
     explicit Engine(int device_id);      // no network: device + stream + scratch for the frame / detector stages only
     ~Engine();
     Engine(const Engine&) = delete;
@@ -130,6 +133,15 @@ class Engine {
     template <typename T> T* upload(const std::vector<T>& v);
     void* upload_bytes(const void* p, size_t nbytes);
     DevPw upload_pw(const HostPw& h);
+    // WHENET_F32S: 1x1 products as binary16 hi/lo pairs (option "split_pw" switches the pointwise kernels between the two forms)
+    void set_split(PwArgs& a, const DevPw& w) const {
+        a.split = split_ && split_pw_ && w.wps != nullptr;
+        a.wps = w.wps;
+        a.KSs = w.KSs;
+        a.wsi = w.wsi;
+    }
+    bool split_ = false;        // the handle was created as WHENET_F32S
+    bool split_pw_ = true;      // option "split_pw"
     void ensure_capacity(int n);
     void release_arena();
     void drop_graphs();
@@ -238,7 +250,7 @@ class Engine {
 
     Slot slots_[WHENET_MAX_INFLIGHT];
     Slot host_slot_;                   // pinned staging of small BLOCKING host forwards (forward_host, n <= host_pinned_max_)
-    int host_pinned_max_ = 32;
+    int host_pinned_max_ = 8;      // measured round 5: pinned wins up to 8 crops (B=1 f32 420 vs 445 us), loses at 16-32
     int next_ticket_ = 0;
 };
 

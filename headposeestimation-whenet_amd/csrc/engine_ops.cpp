@@ -132,6 +132,7 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
         a.N = head_.N;
         a.KS = head_.KS;
         a.NTILES = head_.NTILES;
+        set_split(a, head_);
         a.HW = 49;
         a.act = ACT_SWISH;
         launch_pw(a, dtype_, pw_impl_, num_cus_, stream_);

@@ -102,6 +102,11 @@ struct PwArgs {
     void* out;             // [M][N] T
     int M, K, N, KS, NTILES, HW, act;
     SeFuse se;             // set: the kernel computes the gate of its rows' crops itself (gate must be nullptr)
+    // WHENET_F32S: float storage, products as binary16 hi/lo pairs on the f16 matrix pipe (pw.hip PwOps<float, true>)
+    bool split = false;
+    const void* wps = nullptr;     // [hi image | lo image], f16 fragment order (snapshot.cpp::pack_pw_split)
+    int KSs = 0;                   // ceil(K / 16)
+    float wsi = 1.0f;              // 2^-shift of the scaled weights
 };
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream);
 

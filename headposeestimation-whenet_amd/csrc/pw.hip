@@ -40,6 +40,65 @@ namespace whenet {
 
 namespace {
 
+// Operand forms of the pointwise kernels.
+//   SP = false: operands in the storage type T, one Mfma<T>::step per k-step (f16: 16 k; f32: 8 k on the f32 matrix pipe).
+//   SP = true (T = float; WHENET_F32S, round 5): float32 STORAGE, products on the f16 matrix pipe.  A lane's fragment is 8
+//     consecutive floats of its pixel row (two 16-byte loads, k-step = 16 as in the f16 form); it is split in registers into
+//     binary16 hi = f16(x), lo = f16(x - hi) and multiplied against the host-split weights (snapshot.cpp::pack_pw_split) as
+//     lo_w * hi + hi_w * lo + hi_w * hi -- three v_mfma_f32_32x32x16_f16 per 16 k where the exact form issues eight
+//     v_mfma_f32_32x32x2_f32 (5.3x less matrix time), f32 accumulation as before; the dropped lo*lo term is 2^-22 of the
+//     product.  binary16 subnormal operands are honoured by the matrix cores (tools/probes/mfma_denorm_probe.hip), so the
+//     small lo halves of small activations keep their absolute precision (2^-25).
+template <typename T, bool SP> struct PwOps {
+    static constexpr int V = Vec<T>::V;                     // k elements of a lane's fragment
+    using VT = typename Vec<T>::type;
+    struct A { VT v; };                                     // as loaded
+    struct P { VT v; };                                     // as multiplied
+    struct W { VT v; };
+    static __device__ __forceinline__ A load_a(const T* p) { return A{*reinterpret_cast<const VT*>(p)}; }
+    static __device__ __forceinline__ A zero_a() { return A{vec_zero<T>()}; }
+    static __device__ __forceinline__ void gate(A& a, const T* g) { a.v = a.v * *reinterpret_cast<const VT*>(g); }
+    static __device__ __forceinline__ P prep(const A& a) { return P{a.v}; }
+    // w: the layer's packed image; i: index of the lane's 16-byte fragment in it; lo_off: unused
+    static __device__ __forceinline__ W load_w(const T* w, size_t i, size_t) { return W{reinterpret_cast<const VT*>(w)[i]}; }
+    static __device__ __forceinline__ void step(const W& w, const P& p, float16v& acc) { Mfma<T>::step(w.v, p.v, acc); }
+};
+template <> struct PwOps<float, true> {
+    static constexpr int V = 8;
+    struct A { float4v x0, x1; };
+    struct P { half8 hi, lo; };
+    struct W { half8 hi, lo; };
+    static __device__ __forceinline__ A load_a(const float* p) {
+        return A{*reinterpret_cast<const float4v*>(p), *reinterpret_cast<const float4v*>(p + 4)};
+    }
+    static __device__ __forceinline__ A zero_a() { return A{float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}}; }
+    static __device__ __forceinline__ void gate(A& a, const float* g) {
+        a.x0 = a.x0 * *reinterpret_cast<const float4v*>(g);
+        a.x1 = a.x1 * *reinterpret_cast<const float4v*>(g + 4);
+    }
+    static __device__ __forceinline__ P prep(const A& a) {
+        P p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const half_t h0 = half_t(a.x0[e]), h1 = half_t(a.x1[e]);
+            p.hi[e] = h0;
+            p.hi[4 + e] = h1;
+            p.lo[e] = half_t(a.x0[e] - float(h0));
+            p.lo[4 + e] = half_t(a.x1[e] - float(h1));
+        }
+        return p;
+    }
+    static __device__ __forceinline__ W load_w(const float* w, size_t i, size_t lo_off) {
+        const half8* q = reinterpret_cast<const half8*>(w);
+        return W{q[i], q[lo_off + i]};
+    }
+    static __device__ __forceinline__ void step(const W& w, const P& p, float16v& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo, p.hi, acc, 0, 0, 0);       // (small terms first)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, p.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, p.hi, acc, 0, 0, 0);
+    }
+};
+
 // Deep contractions (K >= 320: the project convs of blocks 7-16 and the head conv, all on 14x14 / 7x7
 // maps, i.e. few rows).  A workgroup owns B2*32 rows x B2*32 out-channels (B2 x B2 MFMA tiles per wave);
 // its 4 waves split the k-steps interleaved (wave p takes k-steps p, p+4, ..) and the four partial
@@ -59,13 +118,15 @@ namespace {
 //     through LDS and runs bias / skip / store for it.
 // GM: 0 = no gate, 1 = gate [n][K] from global memory (block 1, and every block with option se_fuse=0), 2 = the
 // workgroup computes the gate rows of its own crops from the producer's squeeze-excite partial vectors (se_device.h)
-template <typename T, int B2, int GM, bool RES, int ACT>
+template <typename T, int B2, int GM, bool RES, int ACT, bool SP = false>
 __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     const T* __restrict__ A, const T* __restrict__ Wp, const float* __restrict__ bias, const T* __restrict__ gate,
     const T* __restrict__ res, T* __restrict__ out, int M, int K, int N, int KS, int NTILES, int HW, int MT, int NCH,
-    const SeFuse se) {
+    const SeFuse se, float wsi) {
     constexpr bool GATE = GM != 0;
-    constexpr int V = Vec<T>::V;
+    using OPS = PwOps<T, SP>;
+    constexpr int V = OPS::V;                       // k elements per lane and k-step (SP: 8 floats)
+    constexpr int SV = Vec<T>::V;                   // elements of a 16-byte vector of the storage type
     using VT = typename Vec<T>::type;
     using OT = T __attribute__((ext_vector_type(4)));
     constexpr int MB = B2, NT = B2, SK = 4;
@@ -104,17 +165,18 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     const int ncrop = row_last / HW - crop_lo + 1;                     // <= GCROPS
     // gate rows of crops crop_lo .. crop_hi -> LDS, 16 bytes per lane (K is a multiple of 16): all loads issued at once, in front
     // of the first operand group, written to LDS once that group is on its way as well
-    constexpr int GV = GM == 1 ? (GCROPS * GK / V + 255) / 256 : 1;
+    constexpr int GV = GM == 1 ? (GCROPS * GK / SV + 255) / 256 : 1;
     VT gv[GV];
     if constexpr (GM == 1) {
         const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
             const int i = int(threadIdx.x) + j * 256;
-            gv[j] = src[i < ncrop * K / V ? i : 0];
+            gv[j] = src[i < ncrop * K / SV ? i : 0];
         }
     }
-    const VT* wp = reinterpret_cast<const VT*>(Wp) + size_t(nt0) * 64 + lane;
+    const size_t w_lane = size_t(nt0) * 64 + lane;                     // this lane's fragment of tile nt0, k-step 0
+    const size_t w_lo = size_t(KS) * NTILES * 64;                      // (SP) fragments between the hi and the lo image
 
     float16v acc[MB][NT];
 #pragma unroll
@@ -125,7 +187,8 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
             for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.0f;
 
     struct Ops {
-        VT a[U][MB], w[U][NT];
+        typename OPS::A a[U][MB];
+        typename OPS::W w[U][NT];
     };
     // Every load of the k-loop is UNCONDITIONAL (addresses clamped to the last k-step / tile / row; the MFMAs of a k-step past
     // KS or of a tile past NTILES are skipped by wave-uniform branches, rows past M are never stored): with loads under
@@ -136,11 +199,11 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
         for (int u = 0; u < U; ++u) {
             const int k1 = ks + u * SK;
             const int k1c = k1 < KS ? k1 : KS - 1;                     // (wave-uniform)
-            const VT* wk = wp + size_t(k1c) * NTILES * 64;
+            const size_t wk = w_lane + size_t(k1c) * NTILES * 64;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) o.w[u][t] = wk[(nt0 + t < NTILES ? t : 0) * 64];
+            for (int t = 0; t < NT; ++t) o.w[u][t] = OPS::load_w(Wp, wk + (nt0 + t < NTILES ? t : 0) * 64, w_lo);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) o.a[u][mb] = *reinterpret_cast<const VT*>(ap[mb] + k1c * 2 * V);
+            for (int mb = 0; mb < MB; ++mb) o.a[u][mb] = OPS::load_a(ap[mb] + k1c * 2 * V);
         }
     };
     auto compute = [&](const Ops& o, int ks) {
@@ -150,11 +213,12 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
             if (k1 >= KS) continue;                                    // (wave-uniform)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                VT a = o.a[u][mb];
-                if constexpr (GATE) a = a * *reinterpret_cast<const VT*>(gp[mb] + k1 * 2 * V);
+                typename OPS::A a = o.a[u][mb];
+                if constexpr (GATE) OPS::gate(a, gp[mb] + k1 * 2 * V);
+                const typename OPS::P pa = OPS::prep(a);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (nt0 + t < NTILES) Mfma<T>::step(o.w[u][t], a, acc[mb][t]);
+                    if (nt0 + t < NTILES) OPS::step(o.w[u][t], pa, acc[mb][t]);
             }
         }
     };
@@ -168,7 +232,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
             const int i = int(threadIdx.x) + j * 256;
-            if (i < ncrop * K / V) dst[i] = gv[j];
+            if (i < ncrop * K / SV) dst[i] = gv[j];
         }
         lds_barrier();
     }
@@ -242,7 +306,7 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
         OT o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float y = sum[4 * i4 + r] + bv[i4][r];
+            float y = SP ? fmaf(sum[4 * i4 + r], wsi, bv[i4][r]) : sum[4 * i4 + r] + bv[i4][r];
             if constexpr (ACT == ACT_SWISH) y = conv_swish<T>(y);
             if constexpr (RES) y += float(rv[i4][r]);
             o[r] = T(y);
@@ -265,21 +329,24 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
 //     lane stores 16 bytes and a wave-instruction writes whole 128-byte row segments of the
 //     NHWC output (the direct form scatters 8-byte pieces: the write path, not the MFMA, was
 //     what bounded the 6x-expanding layers).
-template <typename T, int NT, int GM, bool RES, int ACT>
+template <typename T, int NT, int GM, bool RES, int ACT, bool SP = false>
 __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict__ A, const T* __restrict__ Wp,
                                                              const float* __restrict__ bias,
                                                              const T* __restrict__ gate,
                                                              const T* __restrict__ res, T* __restrict__ out, int M,
                                                              int K, int N, int KS, int NTILES, int HW, int MT,
-                                                             int NCH, const SeFuse se) {
+                                                             int NCH, const SeFuse se, float wsi) {
     constexpr bool GATE = GM != 0;
     constexpr int TGK = 256;                                // K < 320 here: block 6's 240 is the widest gated layer
     __shared__ __attribute__((aligned(16))) T s_gate[GATE ? 2 * TGK : 8];        // 128 rows touch <= 2 crops (HW >= 196)
     __shared__ float s_r[GM == 2 ? 2 * 12 : 4];
-    constexpr int V = Vec<T>::V;
+    using OPS = PwOps<T, SP>;
+    constexpr int V = OPS::V;                               // k elements per lane and k-step (SP: 8 floats)
+    constexpr int SV = Vec<T>::V;
     using VT = typename Vec<T>::type;
-    constexpr int UK = 4;                                   // k-steps per LDS stage (8: measured -3 % on the K = 32..96 layers)
-    constexpr int STAGE_VECS = UK * NT * 64;                // 16-byte vectors per stage
+    constexpr int UK = SP ? 2 : 4;                          // k-steps per LDS stage (8: measured -3 % on the K = 32..96 layers)
+    constexpr int WT = SP ? 2 * NT : NT;                    // staged fragments per k-step (SP: NT hi + NT lo)
+    constexpr int STAGE_VECS = UK * WT * 64;                // 16-byte vectors per stage
     constexpr int CPT = (STAGE_VECS + 255) / 256;           // staging copies per lane
     constexpr int SW = IsF32<T>::value ? 32 : 64;           // epilogue stage width: 128-byte output rows
     constexpr int TPS = SW / 32;                            // 32-wide tiles per epilogue stage
@@ -324,29 +391,34 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     // it is requested.  Before, the loads sat under per-lane conditions (the compiler waits with vmcnt(0) then) and the gate
     // multiply right behind each load made the "prefetch" of a group four dependent round trips.
     const bool ktail = K % (2 * V) != 0 && g == 1;          // (only un-gated expand convs with Cin = 24 / 40 have one)
-    auto load_raw = [&](int ks) -> VT {
+    using AR = typename OPS::A;
+    using PR = typename OPS::P;
+    auto load_raw = [&](int ks) -> AR {
         const int kc = ks < KS ? ks : KS - 1;
-        VT a = *reinterpret_cast<const VT*>(ap + (ktail && kc == KS - 1 ? -g * V : 0) + kc * 2 * V);
-        if (ktail && kc == KS - 1) a = vec_zero<T>();       // (the bytes past the row; their weights are zero, the bytes may be anything)
+        AR a = OPS::load_a(ap + (ktail && kc == KS - 1 ? -g * V : 0) + kc * 2 * V);
+        if (ktail && kc == KS - 1) a = OPS::zero_a();       // (the bytes past the row; their weights are zero, the bytes may be anything)
         return a;
     };
-    auto gated = [&](VT a, int ks) -> VT {
+    auto gated = [&](AR a, int ks) -> PR {
         if constexpr (GATE)
-            if (ks < KS) a = a * *reinterpret_cast<const VT*>(gp + ks * 2 * V);   // T x T, one rounding (LDS)
-        return a;
+            if (ks < KS) OPS::gate(a, gp + ks * 2 * V);      // T x T, one rounding (LDS)
+        return OPS::prep(a);
     };
 
     VT wreg[CPT];
     static_assert(STAGE_VECS % 256 == 0, "every lane stages whole vectors");
+    const size_t w_lo = size_t(KS) * NTILES * 64;           // (SP) fragments between the hi and the lo image
     auto fetch_w = [&](int grp) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             const int i = c * 256 + tid;
-            const int u = i / (NT * 64);
-            const int j = i - u * (NT * 64);
+            const int u = i / (WT * 64);
+            const int j = i - u * (WT * 64);
             const int ks = grp * UK + u;
-            const int jc = nt0 + (j >> 6) < NTILES ? j : (j & 63);
-            wreg[c] = wsrc[size_t(ks < KS ? ks : KS - 1) * NTILES * 64 + jc];
+            const int tj = j >> 6;                          // staged fragment: tile tj (SP: tj >= NT is tile tj - NT of the lo image)
+            const int tl = SP && tj >= NT ? tj - NT : tj;
+            const int jc = nt0 + tl < NTILES ? tl * 64 + (j & 63) : (j & 63);
+            wreg[c] = wsrc[(SP && tj >= NT ? w_lo : 0) + size_t(ks < KS ? ks : KS - 1) * NTILES * 64 + jc];
         }
     };
     auto store_w = [&](int buf) {
@@ -358,13 +430,14 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     };
 
     const int G = (KS + UK - 1) / UK;
-    VT areg[UK];
+    AR araw[UK];
+    PR areg[UK];
     fetch_w(0);
 #pragma unroll
-    for (int u = 0; u < UK; ++u) areg[u] = load_raw(u);
+    for (int u = 0; u < UK; ++u) araw[u] = load_raw(u);
     const int row_last = (mt * 128 + 128 < M ? mt * 128 + 128 : M) - 1;
     if constexpr (GM == 1) {                                // the gate rows of the <= 2 crops -> LDS (16 bytes per lane)
-        const int cnt = (row_last / HW - crop_lo + 1) * K / V;
+        const int cnt = (row_last / HW - crop_lo + 1) * K / SV;
         const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
         for (int i = tid; i < cnt; i += 256) reinterpret_cast<VT*>(s_gate)[i] = src[i];
     }
@@ -373,11 +446,11 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
     store_w(0);
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < UK; ++u) areg[u] = gated(areg[u], u);
+    for (int u = 0; u < UK; ++u) areg[u] = gated(araw[u], u);
     for (int grp = 0; grp < G; ++grp) {
         // (the last iteration requests a group that does not exist: clamped addresses, an LDS buffer nobody reads -- straight-line
         //  code, so that the compiler counts what is outstanding)
-        VT anext[UK];
+        AR anext[UK];
         fetch_w(grp + 1);
 #pragma unroll
         for (int u = 0; u < UK; ++u) anext[u] = load_raw((grp + 1) * UK + u);
@@ -387,7 +460,16 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
             if (grp * UK + u < KS) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (nt0 + t < NTILES) Mfma<T>::step(wl[(u * NT + t) * 64], areg[u], acc[t]);
+                    if (nt0 + t < NTILES) {
+                        typename OPS::W wf;
+                        if constexpr (SP) {
+                            wf.hi = __builtin_bit_cast(half8, wl[(u * WT + t) * 64]);
+                            wf.lo = __builtin_bit_cast(half8, wl[(u * WT + NT + t) * 64]);
+                        } else {
+                            wf.v = wl[(u * WT + t) * 64];
+                        }
+                        OPS::step(wf, areg[u], acc[t]);
+                    }
             }
         }
         store_w((grp + 1) & 1);
@@ -443,7 +525,7 @@ __global__ __launch_bounds__(256) void whenet_pw_tile_kernel(const T* __restrict
                     float4v y;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc[t < NT ? t : 0][4 * qq + r] + bvs[tt][qq][r];
+                        float v = SP ? fmaf(acc[t < NT ? t : 0][4 * qq + r], wsi, bvs[tt][qq][r]) : acc[t < NT ? t : 0][4 * qq + r] + bvs[tt][qq][r];
                         if constexpr (ACT == ACT_SWISH) v = conv_swish<T>(v);
                         y[r] = (n < N) ? v : 0.f;
                     }
@@ -547,25 +629,25 @@ PwChoice choose_pw(const PwArgs& a, int num_cus) {
     return PwChoice{2, NT, ceil_div(a.NTILES, NT)};
 }
 
-template <typename T, int B2, int GM, bool RES, int ACT>
+template <typename T, int B2, int GM, bool RES, int ACT, bool SP>
 void launch_splitk(const PwArgs& a, hipStream_t stream) {
     const int MT = ceil_div(a.M, 32 * B2), NCH = ceil_div(a.NTILES, B2);
-    hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GM, RES, ACT>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
-                       stream, static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias,
+    hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
+                       stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
                        static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
-                       a.N, a.KS, a.NTILES, a.HW, MT, NCH, a.se);
+                       a.N, SP ? a.KSs : a.KS, a.NTILES, a.HW, MT, NCH, a.se, a.wsi);
 }
 
-template <typename T, int NT, int GM, bool RES, int ACT>
+template <typename T, int NT, int GM, bool RES, int ACT, bool SP>
 void launch_tile(const PwArgs& a, int MT, int NCH, hipStream_t stream) {
     const int blocks = 8 * ceil_div(MT, 8) * NCH;
-    hipLaunchKernelGGL((whenet_pw_tile_kernel<T, NT, GM, RES, ACT>), dim3(blocks), dim3(256), 0, stream,
-                       static_cast<const T*>(a.a), static_cast<const T*>(a.wp), a.bias, static_cast<const T*>(a.gate),
-                       static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, a.KS, a.NTILES, a.HW, MT,
-                       NCH, a.se);
+    hipLaunchKernelGGL((whenet_pw_tile_kernel<T, NT, GM, RES, ACT, SP>), dim3(blocks), dim3(256), 0, stream,
+                       static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias, static_cast<const T*>(a.gate),
+                       static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K, a.N, SP ? a.KSs : a.KS, a.NTILES, a.HW, MT,
+                       NCH, a.se, a.wsi);
 }
 
-template <typename T, int GM, bool RES, int ACT>
+template <typename T, int GM, bool RES, int ACT, bool SP = false>
 void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
     if (impl == 1) {
         WHENET_REQUIRE(GM != 2, WHENET_EINVAL, "pointwise: the check kernel takes the gate from global memory (se_fuse=0)");
@@ -577,32 +659,32 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
     }
     const PwChoice ch = choose_pw(a, num_cus);
     if (ch.kind == 1) {
-        WHENET_REQUIRE(a.K % (2 * Vec<T>::V) == 0, WHENET_EINVAL, "pointwise: a deep contraction is a whole number of k-steps");
-        if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, GM, RES, ACT>(a, stream);
-        else launch_splitk<T, 1, GM, RES, ACT>(a, stream);
+        WHENET_REQUIRE(a.K % (2 * PwOps<T, SP>::V) == 0, WHENET_EINVAL, "pointwise: a deep contraction is a whole number of k-steps");
+        if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, GM, RES, ACT, SP>(a, stream);
+        else launch_splitk<T, 1, GM, RES, ACT, SP>(a, stream);
         return;
     }
     const int MT = ceil_div(a.M, 128);
     switch (ch.NT) {
-        case 1: launch_tile<T, 1, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 2: launch_tile<T, 2, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 3: launch_tile<T, 3, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 4: launch_tile<T, 4, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
-        case 5: launch_tile<T, 5, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
-        default: launch_tile<T, 6, GM, RES, ACT>(a, MT, ch.NCH, stream); break;
+        case 1: launch_tile<T, 1, GM, RES, ACT, SP>(a, MT, ch.NCH, stream); break;
+        case 2: launch_tile<T, 2, GM, RES, ACT, SP>(a, MT, ch.NCH, stream); break;
+        case 3: launch_tile<T, 3, GM, RES, ACT, SP>(a, MT, ch.NCH, stream); break;
+        case 4: launch_tile<T, 4, GM, RES, ACT, SP>(a, MT, ch.NCH, stream); break;
+        case 5: launch_tile<T, 5, GM, RES, ACT, SP>(a, MT, ch.NCH, stream); break;
+        default: launch_tile<T, 6, GM, RES, ACT, SP>(a, MT, ch.NCH, stream); break;
     }
 }
 
-template <typename T>
+template <typename T, bool SP = false>
 void launch_dtype(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
     const bool res = a.res != nullptr;
     const int gm = a.se.rpart != nullptr ? 2 : (a.gate != nullptr ? 1 : 0);
     // the network uses exactly these flavours: expand/head (swish), project (gate from memory | fused SE), + skip
-    if (gm == 0 && !res && a.act == ACT_SWISH) launch_variant<T, 0, false, ACT_SWISH>(a, impl, num_cus, stream);
-    else if (gm == 1 && !res && a.act == ACT_NONE) launch_variant<T, 1, false, ACT_NONE>(a, impl, num_cus, stream);
-    else if (gm == 1 && res && a.act == ACT_NONE) launch_variant<T, 1, true, ACT_NONE>(a, impl, num_cus, stream);
-    else if (gm == 2 && !res && a.act == ACT_NONE) launch_variant<T, 2, false, ACT_NONE>(a, impl, num_cus, stream);
-    else if (gm == 2 && res && a.act == ACT_NONE) launch_variant<T, 2, true, ACT_NONE>(a, impl, num_cus, stream);
+    if (gm == 0 && !res && a.act == ACT_SWISH) launch_variant<T, 0, false, ACT_SWISH, SP>(a, impl, num_cus, stream);
+    else if (gm == 1 && !res && a.act == ACT_NONE) launch_variant<T, 1, false, ACT_NONE, SP>(a, impl, num_cus, stream);
+    else if (gm == 1 && res && a.act == ACT_NONE) launch_variant<T, 1, true, ACT_NONE, SP>(a, impl, num_cus, stream);
+    else if (gm == 2 && !res && a.act == ACT_NONE) launch_variant<T, 2, false, ACT_NONE, SP>(a, impl, num_cus, stream);
+    else if (gm == 2 && res && a.act == ACT_NONE) launch_variant<T, 2, true, ACT_NONE, SP>(a, impl, num_cus, stream);
     else throw Error(WHENET_EINVAL, "pointwise: unsupported epilogue combination");
 }
 
@@ -619,7 +701,11 @@ void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t st
     WHENET_REQUIRE(a.se.rpart == nullptr || (a.se.RP % 4 == 0 && a.se.RP <= 48 && a.se.np >= 1 &&
                                              (a.K >= 320 || (a.K <= 256 && a.HW >= 196 && a.se.RP <= 12))),
                    WHENET_EINVAL, "pointwise: fused squeeze-excite outside its limits");
+    const bool split = a.split && impl == 0;          // (the scalar check kernel multiplies the f32 weights themselves)
+    WHENET_REQUIRE(!a.split || (dtype == WHENET_F32 && a.wps != nullptr && a.KSs == ceil_div(a.K, 16)), WHENET_EINVAL,
+                   "pointwise: the split-product form needs float32 storage and the split weight images");
     if (dtype == WHENET_F16) launch_dtype<half_t>(a, impl, num_cus, stream);
+    else if (split) launch_dtype<float, true>(a, impl, num_cus, stream);
     else launch_dtype<float>(a, impl, num_cus, stream);
     WHENET_HIP_CHECK(hipGetLastError());
 }
@@ -635,9 +721,9 @@ std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
     } else {
         const PwChoice ch = choose_pw(a, num_cus);
         if (ch.kind == 1)
-            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk_kernel<%s, %d, %s, %s, %d>", t,
-                          use_split2(a.M, a.NTILES) ? 2 : 1, gate, res, a.act);
-        else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d>", t, ch.NT, gate, res, a.act);
+            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk_kernel<%s, %d, %s, %s, %d%s>", t,
+                          use_split2(a.M, a.NTILES) ? 2 : 1, gate, res, a.act, a.split ? ", true" : "");
+        else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d%s>", t, ch.NT, gate, res, a.act, a.split ? ", true" : "");
     }
     return buf;
 }

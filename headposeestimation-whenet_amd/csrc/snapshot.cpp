@@ -1,5 +1,6 @@
 #include "snapshot.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -93,6 +94,41 @@ void pack_pw_t(HostPw& pw, const std::vector<double>& wf /*[K][N]*/) {
     for (size_t i = 0; i < pw.dense.size(); ++i) pw.dense[i] = float(T(wf[i]));
 }
 
+// WHENET_F32S operand images (snapshot.h): the folded weights, scaled by a power of two so that the lo halves of the layer's
+// small weights are NORMAL binary16 numbers (|w| ~ 0.05 has lo ~ 1e-5, below 2^-14: its subnormal spacing 2^-24 would cap the
+// pair at ~20 bits), split as hi = f16(w'), lo = f16(w' - hi): hi + lo carries 22 bits of w'.
+void pack_pw_split(HostPw& pw, const std::vector<double>& wf /*[K][N]*/) {
+    const int K = pw.K, N = pw.N;
+    double mx = 0.0;
+    for (double v : wf) mx = std::max(mx, std::fabs(v));
+    int shift = 0;
+    if (mx > 0.0) {
+        shift = int(std::floor(std::log2(16384.0 / mx)));           // largest |w'| in [8192, 16384): far from 65504
+        shift = std::max(-24, std::min(24, shift));
+    }
+    const double sc = std::ldexp(1.0, shift);
+    pw.wsi = float(std::ldexp(1.0, -shift));
+    pw.KS_split = ceil_div(K, 16);
+    const int NTILES = ceil_div(N, 32);
+    const size_t per = size_t(pw.KS_split) * NTILES * 64 * 8;
+    pw.packed_split.assign(2 * per * sizeof(half_t), 0);
+    half_t* hi = reinterpret_cast<half_t*>(pw.packed_split.data());
+    half_t* lo = hi + per;
+    for (int ks = 0; ks < pw.KS_split; ++ks)
+        for (int nt = 0; nt < NTILES; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = nt * 32 + (lane & 31);
+                    const int k = ks * 16 + (lane >> 5) * 8 + e;
+                    const double v = (n < N && k < K) ? wf[size_t(k) * N + n] * sc : 0.0;
+                    const half_t h = half_t(float(v));
+                    const half_t l = half_t(float(v - double(float(h))));
+                    const size_t i = ((size_t(ks) * NTILES + nt) * 64 + lane) * 8 + e;
+                    hi[i] = h;
+                    lo[i] = l;
+                }
+}
+
 // 1x1 conv + BatchNorm as one affine map, in double: wf [K][N] = kernel * bn scale, shift [N]
 struct FoldedPw {
     std::vector<double> wf, shift;
@@ -109,7 +145,7 @@ FoldedPw fold_pw(const std::map<std::string, RawTensor>& t, const std::string& c
     return o;
 }
 
-HostPw pack_pw(const FoldedPw& f, uint32_t K, uint32_t N, int dtype) {
+HostPw pack_pw(const FoldedPw& f, uint32_t K, uint32_t N, int dtype, bool split = false) {
     HostPw pw;
     pw.K = int(K);
     pw.N = int(N);
@@ -117,12 +153,13 @@ HostPw pack_pw(const FoldedPw& f, uint32_t K, uint32_t N, int dtype) {
     for (uint32_t n = 0; n < N; ++n) pw.bias[n] = float(f.shift[n]);
     if (dtype == WHENET_F16) pack_pw_t<half_t>(pw, f.wf);
     else pack_pw_t<float>(pw, f.wf);
+    if (split) pack_pw_split(pw, f.wf);
     return pw;
 }
 
 HostPw make_pw(const std::map<std::string, RawTensor>& t, const std::string& conv, const std::string& bn,
-               uint32_t K, uint32_t N, int dtype) {
-    return pack_pw(fold_pw(t, conv, bn, K, N), K, N, dtype);
+               uint32_t K, uint32_t N, int dtype, bool split = false) {
+    return pack_pw(fold_pw(t, conv, bn, K, N), K, N, dtype, split);
 }
 
 }  // namespace
@@ -174,8 +211,9 @@ std::map<std::string, RawTensor> parse_snapshot(const void* blob, size_t nbytes)
     return out;
 }
 
-HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype) {
-    WHENET_REQUIRE(dtype == WHENET_F32 || dtype == WHENET_F16, WHENET_EINVAL, "dtype must be WHENET_F32 or WHENET_F16");
+HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype, bool split) {
+    WHENET_REQUIRE(dtype == WHENET_F32 || dtype == WHENET_F16, WHENET_EINVAL, "dtype must be WHENET_F32, WHENET_F16 or WHENET_F32S");
+    WHENET_REQUIRE(!split || dtype == WHENET_F32, WHENET_EINVAL, "the split-product form belongs to float32 storage");
     HostModel m;
     m.dtype = dtype;
     m.n_tensors = int(t.size());
@@ -204,7 +242,7 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
         hb.spec = b;
         const std::string p = "b" + std::to_string(b.index);
         const uint32_t cin = b.cin, cexp = b.cexp(), cout = b.cout, k = b.k, r = b.se_reduced();
-        if (b.has_expand()) hb.expand = make_pw(t, p + "/expand", p + "/expand_bn", cin, cexp, dtype);
+        if (b.has_expand()) hb.expand = make_pw(t, p + "/expand", p + "/expand_bn", cin, cexp, dtype, split);
         {
             const float* w = need(t, p + "/dw/kernel", {k, k, cexp, 1}).data;
             Folded f = fold_bn(t, p + "/dw_bn", cexp);
@@ -235,11 +273,11 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype)
                 for (uint32_t c = 0; c < cexp; ++c) hb.se.w2c[size_t(c) * rp + j] = w2[size_t(j) * cexp + c];
             hb.se.b2.assign(b2, b2 + cexp);
         }
-        hb.project = make_pw(t, p + "/project", p + "/project_bn", cexp, cout, dtype);
+        hb.project = make_pw(t, p + "/project", p + "/project_bn", cexp, cout, dtype, split);
         m.blocks.push_back(std::move(hb));
     }
 
-    m.head = make_pw(t, "head/conv", "head/bn", 320, FEAT, dtype);
+    m.head = make_pw(t, "head/conv", "head/bn", 320, FEAT, dtype, split);
 
     {   // Block 1's project (32 -> 16, linear: BN, no activation) followed by block 2's expand (16 -> 96) is ONE affine
         // map of block 1's gated depthwise output (block 2 has no skip, nothing else reads block 1's output):

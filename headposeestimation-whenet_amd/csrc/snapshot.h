@@ -33,6 +33,11 @@ struct HostPw {
     std::vector<float> bias;         // [N]
     std::vector<float> dense;        // [K][N] folded weights rounded to the activation dtype
                                      // (operand of the scalar check kernel, pw_impl=1)
+    // WHENET_F32S (float storage, products on the f16 matrix pipe): w * 2^wshift = hi + lo in binary16, two images in the
+    // f16 fragment order (k-step = 16: lane l <-> n = 32 nt + (l & 31), k = 16 ks + 8 (l >> 5) + e), [hi image | lo image]
+    std::vector<uint8_t> packed_split;
+    int KS_split = 0;
+    float wsi = 1.0f;                // 2^-wshift: the accumulators are multiplied by it in the epilogue
 };
 
 struct HostDw {
@@ -76,6 +81,6 @@ struct HostModel {
     int n_tensors = 0;
 };
 
-HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype);
+HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype, bool split = false);
 
 }  // namespace whenet

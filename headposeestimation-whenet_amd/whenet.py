@@ -17,8 +17,9 @@ Extras that the reference does not have (keyword-only, all optional):
   device=0            GPU ordinal
   devices=[0,1,..]    several GPUs from this one process: one handle + feeder thread per device, the batch of each
                       get_angle call split contiguously over them (whenet_hip/multi.py), same bits
-  dtype='f32'|'f16'   activation / 1x1-weight type (f32 = parity configuration)
-  inflight=1..4       engines per handle that one large get_angle call (N >= 256) is spread over in 128-crop chunks, copies
+  dtype='f32'|'f16'|'f32s'   activation / 1x1-weight type (f32 = parity configuration; f32s = float32 storage with the
+                      1x1 products as binary16 hi/lo pairs on the f16 matrix cores, include/whenet_hip.h WHENET_F32S)
+  inflight=1..4       engines per handle that one large get_angle call (N >= 256) is spread over in 64-crop chunks, copies
                       overlapping forwards (include/whenet_hip.h "fanout_min"); default: 2, created at the first such call
   .predict            alias of get_angle (BASELINE.json words the API as WHENet.predict(crop))
   .last_logits, .last_argmax   what Model.predict returned for the last call, and the bin argmax
@@ -38,7 +39,8 @@ from whenet_hip import _lib, spec  # noqa: E402
 from whenet_hip import weights as _weights  # noqa: E402
 
 _DTYPES = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32,
-           "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16}
+           "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16,
+           "f32s": _lib.F32S}          # float32 storage, 1x1 products as binary16 hi/lo pairs on the f16 matrix cores
 
 
 _as_uint8_crops = _lib.as_uint8_crops

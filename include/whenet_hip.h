@@ -52,6 +52,10 @@ extern "C" {
 /* arithmetic type of activations and 1x1-conv weights (accumulation is always f32) */
 #define WHENET_F32 0            /* parity configuration: <=1e-3 deg vs the float64 oracle   */
 #define WHENET_F16 1            /* throughput configuration (north-star fp16)               */
+#define WHENET_F32S 2           /* float32 storage and accumulation as WHENET_F32, the 1x1 products as binary16 hi/lo pairs on the
+                                 * f16 matrix cores (w = hi + lo, x = hi + lo; lo_w*hi_x + hi_w*lo_x + hi_w*hi_x: ~22 bits per
+                                 * product, 3 f16 MFMAs where WHENET_F32 issues 8 f32 MFMAs).  whenet_info_t.dtype reports
+                                 * WHENET_F32 (the storage type); option "split_pw" 0 runs the exact-f32 kernels on such a handle */
 
 #define WHENET_IMG      224
 #define WHENET_NLOGITS  252     /* 120 yaw | 66 pitch | 66 roll  (whenet.py:11-13)          */
@@ -139,12 +143,13 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  (f16) / 49 (f32) dependent launches: whenet_info_t.n_kernels_per_forward).  The caller gives every forward in flight its own output
  *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
  *          "fanout_min" (>= 0, default 256: a blocking whenet_forward_u8 of at least this many crops is cut into
- *                  "fanout_chunk"-crop forwards (default 128) that travel through the handle's pinned submission slots,
+ *                  "fanout_chunk"-crop forwards (default 64) that travel through the handle's pinned submission slots,
  *                  round-robin over its "inflight" engines, at most "fanout_depth" (1..4, default 2) outstanding per engine:
  *                  the copy of chunk i+1 overlaps the forward of chunk i.  Results are bitwise those of one forward.
  *                  0 = never.  "fanout_stage": 0 = chunks are copied into pinned staging first, 1 = DMA straight from the
- *                  caller's memory (default; measured round 5 with 2 engines: 126 k against 109 k crops/s at N = 512)),
- *          "host_pinned_max" (0..4096, default 32: a blocking whenet_forward_u8 of at most this many crops travels through a
+ *                  caller's memory (default; measured round 5 with 2 engines and 64-crop chunks, two boxes: 115 k crops/s at N = 512
+ *                  against 105 k for the single forward; 128-crop chunks read 126 k on one box and 90 k on the other)),
+ *          "host_pinned_max" (0..4096, default 8: a blocking whenet_forward_u8 of at most this many crops travels through a
  *                  pinned staging slot -- one asynchronous H2D, the forward, three asynchronous D2H, ONE wait -- instead of
  *                  four synchronous copies from / to the caller's pageable memory: the latency path of the reference's
  *                  per-head call shape (demo.py:14, demo_video.py:27)),

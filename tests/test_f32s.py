@@ -1,0 +1,116 @@
+"""WHENET_F32S (round 5): float32 storage and accumulation, the 1x1 products as binary16 hi/lo pairs on the f16 matrix
+cores (pw.hip PwOps<float, true>).  Held to the SAME bar as the exact-f32 configuration: <= 1e-3 deg and equal argmax
+against the float64 oracle on the 512-crop set and against the reference-run fixture; per-kernel tolerance 2e-5; batch
+invariance bitwise."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import whenet_oracle as O
+from tests import refcases as C
+from whenet_hip import _lib, spec, synth, weights as W
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def blob():
+    return W.pack(W.synthetic(1234))
+
+
+@pytest.fixture(scope="module")
+def hs(blob):
+    h = _lib.Handle(blob, device=0, dtype=_lib.F32S)
+    yield h
+    h.close()
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_info_reports_float_storage(hs):
+    assert hs.info().dtype == _lib.F32
+    with pytest.raises(ValueError):
+        with _lib.Handle(W.pack(W.synthetic(1234)), device=0, dtype=_lib.F16) as h16:
+            h16.set_option("split_pw", 1)
+
+
+def test_f32s_meets_the_parity_bar_on_512_crops(hs, blob):
+    fx = np.load(os.path.join(GOLD, "f16_set512_expected.npz"))
+    crops = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])
+    y, a, l = hs.forward(crops)
+    e = np.abs(y - fx["angles"])
+    safe = fx["margins"] > 2e-3
+    with _lib.Handle(blob, device=0, dtype=_lib.F32) as h32:
+        y32, a32, l32 = h32.forward(crops)
+    e32 = np.abs(y32 - fx["angles"])
+    print(f"\n[f32s, 512 crops vs oracle] max {e.max():.2e} mean {e.mean():.2e} deg, max |logit err| {np.abs(l - fx['logits']).max():.2e}"
+          f"   (exact f32: max {e32.max():.2e} mean {e32.mean():.2e} deg, logits {np.abs(l32 - fx['logits']).max():.2e})")
+    assert e.max() <= 1e-3
+    assert np.array_equal(a[safe], fx["argmax"][safe])
+    # split_pw = 0 on the same handle: the exact-f32 kernels, bitwise the WHENET_F32 handle
+    hs.set_option("split_pw", 0)
+    try:
+        y0, a0, l0 = hs.forward(crops[:70])
+    finally:
+        hs.set_option("split_pw", 1)
+    assert np.array_equal(y0, y32[:70]) and np.array_equal(l0, l32[:70])
+
+
+def test_f32s_against_the_reference_run(hs):
+    ref = dict(np.load(os.path.join(GOLD, "reference_get_angle.npz")))
+    crops = C.crops64()
+    y, a, l = hs.forward(crops)
+    assert np.abs(y - ref["n64_angles"]).max() <= 1e-3
+    safe = O.top2_margin(ref["n64_logits"]) > 2e-3
+    assert np.array_equal(a[safe], O.argmax_bins(ref["n64_logits"])[safe])
+
+
+@pytest.mark.parametrize("index", [1, 2, 3, 6, 9, 12, 13, 16])
+def test_f32s_block_kernels_within_f32_tolerance(hs, blob, index):
+    """every pointwise kernel form (tile / split-K x gate from memory / fused gate x skip) on the oracle's own block input"""
+    taps = {}
+    crops = np.load(os.path.join(GOLD, "golden_crops.npy"))[:3]
+    O.forward(crops, W.synthetic(1234), np.float64, taps=taps)
+    b = spec.blocks()[index - 1]
+    x = (taps["stem"] if index == 1 else taps[f"b{index - 1}/out"]).astype(np.float32)
+    for se_fuse in (0, 2):
+        hs.set_option("se_fuse", se_fuse)
+        try:
+            r = hs.op_block(index, x)
+        finally:
+            hs.set_option("se_fuse", 1)
+        assert rel_err(r["out"], taps[f"b{index}/out"]) < 6e-5, (index, se_fuse)
+    hs.set_option("fuse_front", 0)           # the expand conv as a pointwise launch of its own (tile kernel, K = 16..192)
+    try:
+        r = hs.op_block(index, x)
+    finally:
+        hs.set_option("fuse_front", 1)
+    if b.has_expand:
+        assert rel_err(r["expand"], taps[f"b{index}/expand"]) < 2e-5
+    assert rel_err(r["out"], taps[f"b{index}/out"]) < 6e-5
+
+
+def test_f32s_batch_invariance_bitwise(hs):
+    crops = np.concatenate([synth.scene_crops(40, seed=3), synth.noise_crops(37, seed=4)])
+    y, a, l = hs.forward(crops)
+    for n in (1, 2, 3, 16, 17, 21, 64):
+        yn, an, ln = hs.forward(crops[:n])
+        assert np.array_equal(yn, y[:n]) and np.array_equal(ln, l[:n]), n
+    hs.set_option("lanes", 1)
+    try:
+        y1, _, l1 = hs.forward(crops)
+    finally:
+        hs.set_option("lanes", 2)
+    assert np.array_equal(y1, y) and np.array_equal(l1, l)
+
+
+def test_f32s_dropin_class():
+    import whenet
+    ref = dict(np.load(os.path.join(GOLD, "reference_get_angle.npz")))
+    with whenet.WHENet(dtype="f32s") as m:
+        y, p, r = m.get_angle(C.crops64()[:9])
+    assert np.abs(np.stack([y, p, r], 1) - ref["n9_angles"]).max() <= 1e-3
