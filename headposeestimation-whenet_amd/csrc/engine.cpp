@@ -534,6 +534,10 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.pad = sp.pad_before();
         a.KSe = b.expand.KS;
         a.NTe = b.expand.NTILES;
+        a.split = split_ && split_pw_ && b.expand.wps != nullptr;
+        a.weps = b.expand.wps;
+        a.KSes = b.expand.KSs;
+        a.wsi = b.expand.wsi;
         a.n = n;
         a.plan = b.fplan;
         a.plan.threads = front_threads(b.fplan, n);

@@ -44,7 +44,7 @@ constexpr int VC = 4;
 // this kernel used to spend a third of its VALU cycles in them.
 __device__ __forceinline__ int fdiv(int q, float rinv) { return int((float(q) + 0.5f) * rinv); }
 
-template <typename T, int K, int S, int NTHR>
+template <typename T, int K, int S, int NTHR, bool SP = false>
 __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restrict__ x, const T* __restrict__ wep,
                                                             const float* __restrict__ be,
                                                             const float* __restrict__ wd,
@@ -52,10 +52,15 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                                                             float* __restrict__ rpart, int H, int Ho, int Cin,
                                                             int Cexp, int pad, int KSe, int NTe, int CC, int TH,
                                                             int NSX, int tiles_x, int EH, int EW, int EP, int w_off,
-                                                            const float* __restrict__ w1t, int R, int RP) {
-    constexpr int V = Vec<T>::V;
+                                                            const float* __restrict__ w1t, int R, int RP, float wsi) {
+    // SP (T = float, WHENET_F32S): the expand products as binary16 hi/lo pairs on the f16 matrix cores (device_math.h PwOps);
+    // KSe then counts 16-deep k-steps and wep is the [hi | lo] image pair.  Everything behind the expand is unchanged.
+    using OPS = PwOps<T, SP>;
+    constexpr int V = OPS::V;                   // k elements of a lane's operand fragment
     constexpr int SZ = int(sizeof(T));
     using VT = typename Vec<T>::type;
+    using WF = typename OPS::W;
+    using AF = typename OPS::A;
     using OT = T __attribute__((ext_vector_type(4)));
     using VCT = OT;
     constexpr int NIX = (P - 1) * S + K;
@@ -90,12 +95,12 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     const float r_nstrip = __builtin_amdgcn_rcpf(float(nstrip)), r_rw = __builtin_amdgcn_rcpf(float(RW));
 
     const T* xb = x + size_t(b) * H * H * Cin;
-    const VT* wf0 = reinterpret_cast<const VT*>(wep) + size_t(c0 >> 5) * 64;
+    const size_t wf0 = size_t(c0 >> 5) * 64, w_lo = size_t(KSe) * NTe * 64;      // 16-byte fragments
     struct Task {
         bool valid;
         int tl, eoff;
         const T* xrow;
-        const VT* wf;
+        size_t wf;
     };
     auto make_task = [&](int t) -> Task {
         Task k;
@@ -115,24 +120,20 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     // is also 25 % slower although it saves a round trip per task; 5 waves per SIMD (96 registers) is neutral.
     // Keeping the LDS tile E in f32 (no v_cvt_f32_f16 in the taps, -16 % VALU instructions) is 3-40 % SLOWER:
     // the taps then read twice the LDS bytes.  The kernel sits on VALU issue with the LDS pipe half busy.
-    constexpr int PF = 4;
-    auto load_ops = [&](const Task& k, int ks, VT (&w)[PF], VT (&a)[PF]) {
+    constexpr int PF = SP ? 2 : 4;              // (32 k of operands either way)
+    auto load_ops = [&](const Task& k, int ks, WF (&w)[PF], AF (&a)[PF]) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) w[u] = (ks + u < KSe) ? k.wf[(ks + u) * NTe * 64] : vec_zero<T>();
+        for (int u = 0; u < PF; ++u) w[u] = (ks + u < KSe) ? OPS::load_w(wep, k.wf + size_t(ks + u) * NTe * 64, w_lo) : OPS::zero_w();
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            a[u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
-                       ? *reinterpret_cast<const VT*>(k.xrow + (ks + u) * 2 * V)
-                       : vec_zero<T>();
+            a[u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin) ? OPS::load_a(k.xrow + (ks + u) * 2 * V) : OPS::zero_a();
     };
-    auto load_half = [&](const Task& k, int ks, int u0, VT (&w)[PF], VT (&a)[PF]) {      // k-steps ks, ks + 1 -> slots u0, u0 + 1
+    auto load_half = [&](const Task& k, int ks, int u0, WF (&w)[PF], AF (&a)[PF]) {      // k-steps ks, ks + 1 -> slots u0, u0 + 1
 #pragma unroll
-        for (int u = 0; u < PF / 2; ++u) w[u0 + u] = (ks + u < KSe) ? k.wf[(ks + u) * NTe * 64] : vec_zero<T>();
+        for (int u = 0; u < PF / 2; ++u) w[u0 + u] = (ks + u < KSe) ? OPS::load_w(wep, k.wf + size_t(ks + u) * NTe * 64, w_lo) : OPS::zero_w();
 #pragma unroll
         for (int u = 0; u < PF / 2; ++u)
-            a[u0 + u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin)
-                            ? *reinterpret_cast<const VT*>(k.xrow + (ks + u) * 2 * V)
-                            : vec_zero<T>();
+            a[u0 + u] = (k.valid && ks + u < KSe && (ks + u) * 2 * V + g * V < Cin) ? OPS::load_a(k.xrow + (ks + u) * 2 * V) : OPS::zero_a();
     };
     auto load_bias = [&](const Task& k, float4v (&bv)[4]) {
 #pragma unroll
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
             wreg[jt][jc] = (tap < K * K && c < ccur) ? wd[size_t(tap) * Cexp + c0 + c] : 0.f;
         }
     Task cur = make_task(wave);
-    VT w[PF], a[PF];
+    WF w[PF];
+    AF a[PF];
     float4v bv[4];
     if (wave < ntask) {
         load_bias(cur, bv);
@@ -187,11 +189,11 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         for (int ks = 0; ks < KSe; ks += PF) {
 #pragma unroll
             for (int u = 0; u < HF; ++u)
-                if (ks + u < KSe) Mfma<T>::step(w[u], a[u], acc);           // (wave-uniform)
+                if (ks + u < KSe) OPS::step(w[u], OPS::prep(a[u]), acc);    // (wave-uniform)
             if (ks + PF < KSe) load_half(cur, ks + PF, 0, w, a);
 #pragma unroll
             for (int u = HF; u < PF; ++u)
-                if (ks + u < KSe) Mfma<T>::step(w[u], a[u], acc);
+                if (ks + u < KSe) OPS::step(w[u], OPS::prep(a[u]), acc);
             if (ks + PF + HF < KSe) load_half(cur, ks + PF + HF, HF, w, a);
         }
         const Task nxt = make_task(t + NWAVE);
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                 if (cur.tl * 32 + 8 * qq < ccur) {          // (wave-uniform: chunk widths are multiples of 8)
                     OT o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = T(conv_swish<T>(acc[4 * qq + r] + bv[qq][r]));
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = T(conv_swish<T>(SP ? fmaf(acc[4 * qq + r], wsi, bv[qq][r]) : acc[4 * qq + r] + bv[qq][r]));
                     *reinterpret_cast<OT*>(epix + nl * SZ) = o;
                 }
             }
@@ -338,41 +341,41 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     STAMP(6);
 }
 
-template <typename T, int K, int S, int NTHR>
+template <typename T, int K, int S, int NTHR, bool SP = false>
 void launch_t(const FrontArgs& a, hipStream_t stream) {
     const FrontPlan& p = a.plan;
     dim3 grid(p.tiles_x * p.tiles_y, p.chunks, a.n);
     WHENET_REQUIRE(p.lds_bytes <= 160 * 1024, WHENET_EINVAL, "front: the tile plan needs more than 160 KB of LDS");
-    static std::atomic<bool> attr[64];           // (zero-initialised; handles are one per host thread)
+    static std::atomic<bool> attr[64];           // (zero-initialised, one per instantiation; handles are one per host thread)
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
     if (p.lds_bytes > 64 * 1024 && dev >= 0 && dev < 64 && !attr[dev].load(std::memory_order_acquire)) {
-        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S, NTHR>),
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S, NTHR, SP>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR>), grid, dim3(NTHR), p.lds_bytes, stream,
-                       static_cast<const T*>(a.x), static_cast<const T*>(a.wep), a.be, a.wd, a.bd,
-                       static_cast<T*>(a.out), a.rpart, a.H, a.Ho, a.Cin, a.Cexp, a.pad, a.KSe, a.NTe, p.CC, p.TH, p.NSX,
-                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3);
+    hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR, SP>), grid, dim3(NTHR), p.lds_bytes, stream,
+                       static_cast<const T*>(a.x), static_cast<const T*>(SP ? a.weps : a.wep), a.be, a.wd, a.bd,
+                       static_cast<T*>(a.out), a.rpart, a.H, a.Ho, a.Cin, a.Cexp, a.pad, SP ? a.KSes : a.KSe, a.NTe, p.CC, p.TH, p.NSX,
+                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3, a.wsi);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
-template <typename T, int NTHR>
+template <typename T, int NTHR, bool SP = false>
 void launch_ks(const FrontArgs& a, hipStream_t stream) {
-    if (a.k == 3 && a.s == 1) launch_t<T, 3, 1, NTHR>(a, stream);
-    else if (a.k == 3 && a.s == 2) launch_t<T, 3, 2, NTHR>(a, stream);
-    else if (a.k == 5 && a.s == 1) launch_t<T, 5, 1, NTHR>(a, stream);
-    else if (a.k == 5 && a.s == 2) launch_t<T, 5, 2, NTHR>(a, stream);
+    if (a.k == 3 && a.s == 1) launch_t<T, 3, 1, NTHR, SP>(a, stream);
+    else if (a.k == 3 && a.s == 2) launch_t<T, 3, 2, NTHR, SP>(a, stream);
+    else if (a.k == 5 && a.s == 1) launch_t<T, 5, 1, NTHR, SP>(a, stream);
+    else if (a.k == 5 && a.s == 2) launch_t<T, 5, 2, NTHR, SP>(a, stream);
     else throw Error(WHENET_EINVAL, "front: unsupported kernel/stride");
 }
 
-template <typename T>
+template <typename T, bool SP = false>
 void launch_thr(const FrontArgs& a, hipStream_t stream) {
     switch (a.plan.threads) {
-        case 256: launch_ks<T, 256>(a, stream); break;
-        case 512: launch_ks<T, 512>(a, stream); break;
-        case 1024: launch_ks<T, 1024>(a, stream); break;
+        case 256: launch_ks<T, 256, SP>(a, stream); break;
+        case 512: launch_ks<T, 512, SP>(a, stream); break;
+        case 1024: launch_ks<T, 1024, SP>(a, stream); break;
         default: throw Error(WHENET_EINVAL, "front: threads must be 256, 512 or 1024");
     }
 }
@@ -555,7 +558,10 @@ int front_threads(const FrontPlan& p, int n) {
 }
 
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream) {
+    WHENET_REQUIRE(!a.split || (dtype == WHENET_F32 && a.weps != nullptr && a.KSes == ceil_div(a.Cin, 16)), WHENET_EINVAL,
+                   "front: the split-product form needs float32 storage and the split weight images");
     if (dtype == WHENET_F16) launch_thr<half_t>(a, stream);
+    else if (a.split) launch_thr<float, true>(a, stream);
     else launch_thr<float>(a, stream);
 }
 

@@ -205,6 +205,11 @@ struct FrontArgs {
     int R;
     int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
     FrontPlan plan;
+    // WHENET_F32S: the expand's products as binary16 hi/lo pairs (device_math.h PwOps<float, true>)
+    bool split = false;
+    const void* weps = nullptr;    // [hi image | lo image] of the expand weights
+    int KSes = 0;                  // ceil(Cin / 16)
+    float wsi = 1.0f;
 };
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);

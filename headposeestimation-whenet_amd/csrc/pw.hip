@@ -40,65 +40,6 @@ namespace whenet {
 
 namespace {
 
-// Operand forms of the pointwise kernels.
-//   SP = false: operands in the storage type T, one Mfma<T>::step per k-step (f16: 16 k; f32: 8 k on the f32 matrix pipe).
-//   SP = true (T = float; WHENET_F32S, round 5): float32 STORAGE, products on the f16 matrix pipe.  A lane's fragment is 8
-//     consecutive floats of its pixel row (two 16-byte loads, k-step = 16 as in the f16 form); it is split in registers into
-//     binary16 hi = f16(x), lo = f16(x - hi) and multiplied against the host-split weights (snapshot.cpp::pack_pw_split) as
-//     lo_w * hi + hi_w * lo + hi_w * hi -- three v_mfma_f32_32x32x16_f16 per 16 k where the exact form issues eight
-//     v_mfma_f32_32x32x2_f32 (5.3x less matrix time), f32 accumulation as before; the dropped lo*lo term is 2^-22 of the
-//     product.  binary16 subnormal operands are honoured by the matrix cores (tools/probes/mfma_denorm_probe.hip), so the
-//     small lo halves of small activations keep their absolute precision (2^-25).
-template <typename T, bool SP> struct PwOps {
-    static constexpr int V = Vec<T>::V;                     // k elements of a lane's fragment
-    using VT = typename Vec<T>::type;
-    struct A { VT v; };                                     // as loaded
-    struct P { VT v; };                                     // as multiplied
-    struct W { VT v; };
-    static __device__ __forceinline__ A load_a(const T* p) { return A{*reinterpret_cast<const VT*>(p)}; }
-    static __device__ __forceinline__ A zero_a() { return A{vec_zero<T>()}; }
-    static __device__ __forceinline__ void gate(A& a, const T* g) { a.v = a.v * *reinterpret_cast<const VT*>(g); }
-    static __device__ __forceinline__ P prep(const A& a) { return P{a.v}; }
-    // w: the layer's packed image; i: index of the lane's 16-byte fragment in it; lo_off: unused
-    static __device__ __forceinline__ W load_w(const T* w, size_t i, size_t) { return W{reinterpret_cast<const VT*>(w)[i]}; }
-    static __device__ __forceinline__ void step(const W& w, const P& p, float16v& acc) { Mfma<T>::step(w.v, p.v, acc); }
-};
-template <> struct PwOps<float, true> {
-    static constexpr int V = 8;
-    struct A { float4v x0, x1; };
-    struct P { half8 hi, lo; };
-    struct W { half8 hi, lo; };
-    static __device__ __forceinline__ A load_a(const float* p) {
-        return A{*reinterpret_cast<const float4v*>(p), *reinterpret_cast<const float4v*>(p + 4)};
-    }
-    static __device__ __forceinline__ A zero_a() { return A{float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}}; }
-    static __device__ __forceinline__ void gate(A& a, const float* g) {
-        a.x0 = a.x0 * *reinterpret_cast<const float4v*>(g);
-        a.x1 = a.x1 * *reinterpret_cast<const float4v*>(g + 4);
-    }
-    static __device__ __forceinline__ P prep(const A& a) {
-        P p;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const half_t h0 = half_t(a.x0[e]), h1 = half_t(a.x1[e]);
-            p.hi[e] = h0;
-            p.hi[4 + e] = h1;
-            p.lo[e] = half_t(a.x0[e] - float(h0));
-            p.lo[4 + e] = half_t(a.x1[e] - float(h1));
-        }
-        return p;
-    }
-    static __device__ __forceinline__ W load_w(const float* w, size_t i, size_t lo_off) {
-        const half8* q = reinterpret_cast<const half8*>(w);
-        return W{q[i], q[lo_off + i]};
-    }
-    static __device__ __forceinline__ void step(const W& w, const P& p, float16v& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo, p.hi, acc, 0, 0, 0);       // (small terms first)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, p.lo, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi, p.hi, acc, 0, 0, 0);
-    }
-};
-
 // Deep contractions (K >= 320: the project convs of blocks 7-16 and the head conv, all on 14x14 / 7x7
 // maps, i.e. few rows).  A workgroup owns B2*32 rows x B2*32 out-channels (B2 x B2 MFMA tiles per wave);
 // its 4 waves split the k-steps interleaved (wave p takes k-steps p, p+4, ..) and the four partial

@@ -33,5 +33,5 @@ for name, dt in (("f32", _lib.F32), ("f32s", _lib.F32S), ("f16", _lib.F16)):
             agg.setdefault(p["kind"], 0.0); agg[p["kind"]] += p["avg_us"]
         print(name, "per-kind us (one chain per lane):", {k: round(v, 1) for k, v in agg.items()}, flush=True)
         for p in prof:
-            if p["kind"] == "pw": print(f"   {p['layer']:14s} {p['avg_us']:7.1f} us  {p['kernel']}", flush=True)
+            if p["kind"] in ("pw", "front"): print(f"   {p['layer']:14s} {p['avg_us']:7.1f} us  {p['kernel']}", flush=True)
     h.close()
