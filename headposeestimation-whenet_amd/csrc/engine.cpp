@@ -476,9 +476,12 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.Cin = sp.cin;
         a.Cexp = cexp;
         a.NTe = b.expand.NTILES;
+        a.split = split_ && split_pw_ && b.expand.wps != nullptr;
+        a.weps = b.expand.wps;
+        a.wsi = b.expand.wsi;
         a.n = n;
         a.plan = front7_plan_for(dtype_, sp.cin, cexp, n);
-        R(p + "/front", "front", kernel_name_front7(dtype_, sp.k, a.plan).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
+        R(p + "/front", "front", kernel_name_front7(dtype_, sp.k, a.plan, a.split).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front7(a, s); });
     } else if (use_f2) {
         Front2Args a{};
@@ -701,8 +704,11 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.K = head_.K;
         a.N = head_.N;
         a.NTILES = head_.NTILES;
+        a.split = split_ && split_pw_ && head_.wps != nullptr;
+        a.weps = head_.wps;
+        a.wsi = head_.wsi;
         a.n = n;
-        R("head", "pw", kernel_name_head7(dtype_, n).c_str(), double(n) * (49.0 * a.K * es + a.N * 4.0), 2.0 * n * 49.0 * a.K * a.N,
+        R("head", "pw", kernel_name_head7(dtype_, n, a.split).c_str(), double(n) * (49.0 * a.K * es + a.N * 4.0), 2.0 * n * 49.0 * a.K * a.N,
           [&] { launch_head7(a, s); });
         HeadsArgs hargs{};
         hargs.feat_in = reinterpret_cast<const float*>(v.hc);

@@ -117,6 +117,9 @@ void Engine::op_head(const float* in, int n, float* feat, float* logits, float* 
         a.K = head_.K;
         a.N = head_.N;
         a.NTILES = head_.NTILES;
+        a.split = split_ && split_pw_ && head_.wps != nullptr;
+        a.weps = head_.wps;
+        a.wsi = head_.wsi;
         a.n = n;
         launch_head7(a, stream_);
         h.feat_in = d_feat;

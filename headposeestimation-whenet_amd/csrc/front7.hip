@@ -55,6 +55,7 @@ struct F7Params {
     const float* w1t;                  // [R][Cexp]
     int n, Cin, Cexp, NTe, R, RPse;
     int off_w, off_stage, off_red, off_sum;
+    float wsi;                         // WHENET_F32S: 2^-shift of the scaled split weights (wep is then the [hi | lo] image pair)
 };
 
 // K: depthwise kernel size (3 | 5); KS: k-steps of the expand contraction (Cin / 16); G: crops per workgroup; CC: expanded
@@ -324,7 +325,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
 //     of front.hip's and dw.hip's;
 //   * outputs are stored directly (64 contiguous bytes per pixel and 16-channel block).
 // KS8 = Cin / 8 k-steps.
-template <int K, int KS8, int G, int CC, int NTHR>
+// SP (WHENET_F32S, round 5): the expand products as binary16 hi/lo pairs on the f16 matrix cores (device_math.h PwOps<float, true>):
+// KS8 / 2 k-steps of 16, three v_mfma_f32_32x32x16_f16 each; the staged weights are [k-step][tile][hi | lo][64 lanes] half8 -- the
+// same bytes; the strip's rows are split ONCE when they arrive and serve every channel tile.  Taps, sums and stores unchanged.
+template <int K, int KS8, int G, int CC, int NTHR, bool SP = false>
 __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params p) {
     constexpr int NWAVE = NTHR / 64;
     constexpr int PAD = K / 2;
@@ -349,15 +353,22 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
     // ---- prologue: expand weights -> LDS; this wave's strip of pixel rows -> registers (all 24 k-steps: one round trip) --
     constexpr int nwv = KS8 * NT * 64;
     constexpr int WV = (nwv + NTHR - 1) / NTHR;
+    constexpr int KS16 = KS8 / 2;
     float4v wstage[WV];
     {
         const float4v* src = reinterpret_cast<const float4v*>(p.wep);
+        const size_t w_lo = size_t(KS16) * p.NTe * 64;
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * NTHR;
             if (v < nwv) {
-                const int ks = v / (NT * 64), r = v % (NT * 64);
-                wstage[i] = src[(size_t(ks) * p.NTe + (c0 >> 5)) * 64 + r];
+                if constexpr (SP) {                            // v = ((ks * NT + t) * 2 + h) * 64 + lane
+                    const int l = v & 63, h = (v >> 6) & 1, kt = v >> 7, ks = kt / NT, t = kt % NT;
+                    wstage[i] = src[(h ? w_lo : 0) + (size_t(ks) * p.NTe + (c0 >> 5) + t) * 64 + l];
+                } else {
+                    const int ks = v / (NT * 64), r = v % (NT * 64);
+                    wstage[i] = src[(size_t(ks) * p.NTe + (c0 >> 5)) * 64 + r];
+                }
             }
         }
     }
@@ -370,18 +381,28 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
         gc = gc < nlast ? gc : nlast;
         int px = lm & 7;
         px = px < 7 ? px : 6;
-        return unsigned((gc * 49 + row * 7 + px) * Cin + g * 4) * 4u;
+        return unsigned((gc * 49 + row * 7 + px) * Cin + g * (SP ? 8 : 4)) * 4u;
     };
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
-    float4v a[KS8];
+    using OPS = PwOps<float, true>;
+    float4v a[SP ? 1 : KS8];
+    OPS::P ap[SP ? KS16 : 1];                                  // SP: the strip's rows as binary16 hi / lo fragments
+    auto load_rows = [&](unsigned off) {
+        if constexpr (SP) {
+            OPS::A raw[KS16];
+#pragma unroll
+            for (int ks = 0; ks < KS16; ++ks) raw[ks] = OPS::load_a(reinterpret_cast<const float*>(xb + off + ks * 64));
+#pragma unroll
+            for (int ks = 0; ks < KS16; ++ks) ap[ks] = OPS::prep(raw[ks]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS8; ++ks) a[ks] = *reinterpret_cast<const float4v*>(xb + off + ks * 32);
+        }
+    };
     constexpr bool SPLIT = nstrip * NT <= NWAVE;               // (as the f16 kernel: one (strip, tile) task per wave)
     int strip = SPLIT ? (wave < nstrip * NT ? wave % nstrip : nstrip) : wave;
     const int t_lo = SPLIT ? wave / nstrip : 0, t_hi = SPLIT ? t_lo + 1 : NT;
-    if (strip < nstrip) {
-        const unsigned off = a_offset(strip);
-#pragma unroll
-        for (int ks = 0; ks < KS8; ++ks) a[ks] = *reinterpret_cast<const float4v*>(xb + off + ks * 32);
-    }
+    if (strip < nstrip) load_rows(a_offset(strip));
     float bias_t[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias_t[t] = p.be[c0 + t * 32 + lm];
@@ -404,11 +425,22 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
             float16v acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            if constexpr (SP) {
 #pragma unroll
-            for (int ks = 0; ks < KS8; ++ks) {
-                const float4v w = Wl[(ks * NT + t) * 64 + lane];
+                for (int ks = 0; ks < KS16; ++ks) {
+                    const half8 whi = __builtin_bit_cast(half8, Wl[((ks * NT + t) * 2) * 64 + lane]);
+                    const half8 wlo = __builtin_bit_cast(half8, Wl[((ks * NT + t) * 2 + 1) * 64 + lane]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[ks].hi, wlo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[ks].lo, whi, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[ks].hi, whi, acc, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][u], w[u], acc, 0, 0, 0);
+                for (int ks = 0; ks < KS8; ++ks) {
+                    const float4v w = Wl[(ks * NT + t) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][u], w[u], acc, 0, 0, 0);
+                }
             }
             const float bias = bias_t[t];
             const int ch = t * 32 + lm, cb = ch >> 4, cl = ch & 15;
@@ -420,18 +452,14 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
                     const int jq = cr >> 2, j = cr & 3;
                     float4v o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = conv_swish<float>(acc[4 * qq + r] + bias);
+                    for (int r = 0; r < 4; ++r) o[r] = conv_swish<float>(SP ? fmaf(acc[4 * qq + r], p.wsi, bias) : acc[4 * qq + r] + bias);
                     if (g) o[3] = 0.f;                          // pixel slot 7 is 'SAME' padding of the EXPANDED tensor
                     unsigned char* ep = E + ((((jq * NCB + cb) * ROWS + row) * 64 + j * 16 + (cl ^ (j << 2))) << 5) + g * 16;
                     *reinterpret_cast<float4v*>(ep) = o;
                 }
             }
         }
-        if (more) {
-            const unsigned off = a_offset(strip + NWAVE);
-#pragma unroll
-            for (int ks = 0; ks < KS8; ++ks) a[ks] = *reinterpret_cast<const float4v*>(xb + off + ks * 32);
-        }
+        if (more) load_rows(a_offset(strip + NWAVE));
     }
 
     // ---- depthwise taps on the VALU: items (crop quad, 16-channel block, x-group); lane = channel cl x crop j ------------
@@ -553,12 +581,13 @@ struct OncePerDevice7 {
     OncePerDevice7() { for (auto& d : done) d.store(false, std::memory_order_relaxed); }
 };
 
-template <int K, int KS, int G, int CC, int NTHR, bool F32>
+template <int K, int KS, int G, int CC, int NTHR, bool F32, bool SP = false>
 void launch_f7(const Front7Args& a, hipStream_t stream) {
     const Front7Plan& pl = a.plan;
     F7Params p{};
     p.x = a.x;
-    p.wep = a.wep;
+    p.wep = SP ? a.weps : a.wep;
+    p.wsi = a.wsi;
     p.be = a.be;
     p.wdt = a.wdt;
     p.bd = a.bd;
@@ -573,7 +602,7 @@ void launch_f7(const Front7Args& a, hipStream_t stream) {
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
     auto kern = [] {
-        if constexpr (F32) return &whenet_front7_f32_kernel<K, KS, G, CC, NTHR>;
+        if constexpr (F32) return &whenet_front7_f32_kernel<K, KS, G, CC, NTHR, SP>;
         else return &whenet_front7_kernel<K, KS, G, CC, NTHR>;
     }();
     if (dev >= 0 && dev < 64 && !attr.done[dev].load(std::memory_order_acquire)) {
@@ -631,7 +660,8 @@ void launch_front7(const Front7Args& a, hipStream_t stream) {
     const int key = ((a.k * 10 + a.plan.G) * 1000 + a.plan.CC) * 1000 + a.plan.threads;
     if (a.dtype == WHENET_F32) {
         switch (key) {
-#define F7_CASE32(K, G, CC, T) case ((K * 10 + G) * 1000 + CC) * 1000 + T: launch_f7<K, 24, G, CC, T, true>(a, stream); break;
+#define F7_CASE32(K, G, CC, T) case ((K * 10 + G) * 1000 + CC) * 1000 + T: \
+        if (a.split) launch_f7<K, 24, G, CC, T, true, true>(a, stream); else launch_f7<K, 24, G, CC, T, true>(a, stream); break;
             F7_CASE32(5, 4, 64, 512) F7_CASE32(3, 4, 64, 512)
             F7_CASE32(5, 2, 64, 512) F7_CASE32(3, 2, 64, 512)
             F7_CASE32(5, 1, 64, 512) F7_CASE32(3, 1, 64, 512)
@@ -660,10 +690,10 @@ void launch_front7(const Front7Args& a, hipStream_t stream) {
     }
 }
 
-std::string kernel_name_front7(int dtype, int k, const Front7Plan& p) {
+std::string kernel_name_front7(int dtype, int k, const Front7Plan& p, bool split) {
     return std::string(dtype == WHENET_F32 ? "whenet_front7_f32_kernel<" : "whenet_front7_kernel<") + std::to_string(k) +
            (dtype == WHENET_F32 ? ", 24, " : ", 12, ") + std::to_string(p.G) + ", " + std::to_string(p.CC) + ", " +
-           std::to_string(p.threads) + ">";
+           std::to_string(p.threads) + (dtype == WHENET_F32 ? (split ? ", true>" : ", false>") : ">");
 }
 
 }  // namespace whenet

@@ -142,14 +142,21 @@ __global__ __launch_bounds__(NTHR) void whenet_head7_kernel(const half_t* __rest
 // read it back: 50 + 15 us per 64 crops.
 constexpr int H7F_KS = H7_K / 8, H7F_NC = 32, H7F_KG = 5, H7F_NGRP = H7F_KS / H7F_KG;
 
-template <int G>
+// SP (WHENET_F32S, round 5): the same kernel with the products as binary16 hi/lo pairs on the f16 matrix cores
+// (device_math.h PwOps<float, true>): 20 k-steps of 16, three v_mfma_f32_32x32x16_f16 each instead of eight v_mfma_f32_32x32x2_f32;
+// the LDS image is [k-step][hi | lo][64 lanes] half8 -- the same 40 KB; wsi = 2^-shift of the scaled weights.
+template <int G, bool SP>
 __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* __restrict__ x, const float* __restrict__ wep,
                                                                    const float* __restrict__ bias, float* __restrict__ feat, int n,
-                                                                   int NTILES, int N) {
-    constexpr int NTHR = 128 * G, nstrip = 2 * G, KS = H7F_KS, NC = H7F_NC, KG = H7F_KG, NGRP = H7F_NGRP;
+                                                                   int NTILES, int N, float wsi) {
+    constexpr int NTHR = 128 * G, nstrip = 2 * G, NC = H7F_NC, KG = H7F_KG;
+    constexpr int KS = SP ? H7_K / 16 : H7F_KS;                                  // k-steps: 20 of 16 | 40 of 8
+    constexpr int NGRP = KS / KG;
+    constexpr int KF = SP ? 16 : 8;                                              // floats of a pixel row per k-step
+    (void)nstrip;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const float4v* Wl = reinterpret_cast<const float4v*>(smem);                 // [KS][64 lanes]
-    float* s_gap = reinterpret_cast<float*>(smem + KS * 1024);                  // [nstrip][2 (g)][NC]
+    const float4v* Wl = reinterpret_cast<const float4v*>(smem);                 // f32: [KS][64 lanes]; SP: [KS][2][64 lanes] (16 B each)
+    float* s_gap = reinterpret_cast<float*>(smem + H7F_KS * 1024);              // [nstrip][2 (g)][NC]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,27 +165,31 @@ __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* 
     const int c0 = blockIdx.x * NC;
     const int crop0 = blockIdx.y * G;
 
-    constexpr int nwv = KS * 64;
+    constexpr int nwv = H7F_KS * 64;                                            // 16-byte vectors of the staged image (both forms)
     static_assert(nwv % NTHR == 0, "weight staging: whole vectors per lane");
     constexpr int WV = nwv / NTHR;
     float4v wstage[WV];
     {
         const float4v* src = reinterpret_cast<const float4v*>(wep);
+        const size_t w_lo = size_t(KS) * NTILES * 64;
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int v = tid + i * NTHR;
-            wstage[i] = src[(size_t(v >> 6) * NTILES + (c0 >> 5)) * 64 + (v & 63)];
+            if constexpr (SP) wstage[i] = src[(((v >> 6) & 1) ? w_lo : 0) + (size_t(v >> 7) * NTILES + (c0 >> 5)) * 64 + (v & 63)];
+            else wstage[i] = src[(size_t(v >> 6) * NTILES + (c0 >> 5)) * 64 + (v & 63)];
         }
     }
     int gc = crop0 + (strip >> 1);
     gc = gc < n - 1 ? gc : n - 1;
     int pxl = (strip & 1) * 32 + lm;
     pxl = pxl < H7_HW ? pxl : H7_HW - 1;                        // (idle rows: any valid address, masked out of the sum)
-    const float* xr = x + (size_t(gc) * H7_HW + pxl) * H7_K + g * 4;
-    float4v a0[KG], a1[KG];
-    auto load_group = [&](float4v (&a)[KG], int grp) {
+    const float* xr = x + (size_t(gc) * H7_HW + pxl) * H7_K + g * (KF / 2);
+    using OPS = PwOps<float, SP>;
+    using AF = typename OPS::A;
+    AF a0[KG], a1[KG];
+    auto load_group = [&](AF (&a)[KG], int grp) {
 #pragma unroll
-        for (int u = 0; u < KG; ++u) a[u] = *reinterpret_cast<const float4v*>(xr + (grp * KG + u) * 8);
+        for (int u = 0; u < KG; ++u) a[u] = OPS::load_a(xr + (grp * KG + u) * KF);
     };
     load_group(a0, 0);
     const float bias_v = bias[c0 + lm];
@@ -192,12 +203,21 @@ __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* 
     float16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    auto compute = [&](const float4v (&a)[KG], int grp) {
+    auto compute = [&](const AF (&a)[KG], int grp) {
 #pragma unroll
         for (int u = 0; u < KG; ++u) {
-            const float4v w = Wl[(grp * KG + u) * 64 + lane];
+            if constexpr (SP) {
+                const half8 whi = __builtin_bit_cast(half8, Wl[((grp * KG + u) * 2) * 64 + lane]);
+                const half8 wlo = __builtin_bit_cast(half8, Wl[((grp * KG + u) * 2 + 1) * 64 + lane]);
+                const typename OPS::P pa = OPS::prep(a[u]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa.hi, wlo, acc, 0, 0, 0);       // (operand roles swapped: rows = pixels)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa.lo, whi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa.hi, whi, acc, 0, 0, 0);
+            } else {
+                const float4v w = Wl[(grp * KG + u) * 64 + lane];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], w[t], acc, 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].v[t], w[t], acc, 0, 0, 0);
+            }
         }
     };
 #pragma unroll
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int px = (strip & 1) * 32 + 8 * (r >> 2) + 4 * g + (r & 3);      // this value's pixel of the crop
-        const float y = conv_swish<float>(acc[r] + bias_v);
+        const float y = conv_swish<float>(SP ? fmaf(acc[r], wsi, bias_v) : acc[r] + bias_v);
         sum += (px < H7_HW) ? y : 0.f;
     }
     s_gap[(strip * 2 + g) * NC + lm] = sum;
@@ -233,8 +253,12 @@ __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* 
 template <int G>
 void launch_h7_f32(const Head7Args& a, hipStream_t stream) {
     const size_t lds = size_t(H7F_KS) * 1024 + size_t(2 * G) * 2 * H7F_NC * 4;
-    hipLaunchKernelGGL((whenet_head7_f32_kernel<G>), dim3(a.N / H7F_NC, ceil_div(a.n, G)), dim3(128 * G), lds, stream,
-                       static_cast<const float*>(a.x), static_cast<const float*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N);
+    if (a.split)
+        hipLaunchKernelGGL((whenet_head7_f32_kernel<G, true>), dim3(a.N / H7F_NC, ceil_div(a.n, G)), dim3(128 * G), lds, stream,
+                           static_cast<const float*>(a.x), static_cast<const float*>(a.weps), a.bias, a.feat, a.n, a.NTILES, a.N, a.wsi);
+    else
+        hipLaunchKernelGGL((whenet_head7_f32_kernel<G, false>), dim3(a.N / H7F_NC, ceil_div(a.n, G)), dim3(128 * G), lds, stream,
+                           static_cast<const float*>(a.x), static_cast<const float*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N, 1.0f);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
@@ -267,9 +291,9 @@ void launch_head7(const Head7Args& a, hipStream_t stream) {
     }
 }
 
-std::string kernel_name_head7(int dtype, int n) {
+std::string kernel_name_head7(int dtype, int n, bool split) {
     if (dtype == WHENET_F16) return std::string("whenet_head7_kernel<") + (n <= 16 ? "2" : "4") + ", 512>";
-    return std::string("whenet_head7_f32_kernel<") + (n <= 16 ? "2" : "4") + ">";
+    return std::string("whenet_head7_f32_kernel<") + (n <= 16 ? "2" : "4") + (split ? ", true>" : ", false>");
 }
 
 }  // namespace whenet

@@ -141,10 +141,14 @@ struct Head7Args {
     const float* bias;     // [N]
     float* feat;           // [n][N] pooled features, f32
     int K, N, NTILES, n;
+    // WHENET_F32S: products as binary16 hi/lo pairs (device_math.h PwOps<float, true>)
+    bool split = false;
+    const void* weps = nullptr;    // [hi image | lo image]
+    float wsi = 1.0f;
 };
 bool head7_supported(int dtype, int K, int N, int HW);
 void launch_head7(const Head7Args& a, hipStream_t stream);
-std::string kernel_name_head7(int dtype, int n);
+std::string kernel_name_head7(int dtype, int n, bool split = false);
 
 // ---- stemdw.hip -------------------------------------------------------------------------
 // stem conv + BN + Swish fused with block 1's depthwise 3x3 + BN + Swish (whenet.py:8, 23-26), f16 and f32: the 112 x 112 x 32 stem
@@ -282,9 +286,13 @@ struct Front7Args {
     int R;
     int k, Cin, Cexp, NTe, n;
     Front7Plan plan;
+    // WHENET_F32S: the expand's products as binary16 hi/lo pairs (device_math.h PwOps<float, true>)
+    bool split = false;
+    const void* weps = nullptr;    // [hi image | lo image] of the expand weights
+    float wsi = 1.0f;
 };
 void launch_front7(const Front7Args& a, hipStream_t stream);
-std::string kernel_name_front7(int dtype, int k, const Front7Plan& p);
+std::string kernel_name_front7(int dtype, int k, const Front7Plan& p, bool split = false);
 
 // ---- yolo.hip ---------------------------------------------------------------------------
 // YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.

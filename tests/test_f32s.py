@@ -94,6 +94,26 @@ def test_f32s_block_kernels_within_f32_tolerance(hs, blob, index):
     assert rel_err(r["out"], taps[f"b{index}/out"]) < 6e-5
 
 
+def test_f32s_head_conv_and_pooling(hs):
+    taps = {}
+    crops = np.load(os.path.join(GOLD, "golden_crops.npy"))[:5]
+    w = W.synthetic(1234)
+    r = O.forward(crops, w, np.float64, taps=taps)
+    x = taps["b16/out"].astype(np.float32)
+    got = hs.op_head(x)
+    feat = O.swish(O.batchnorm(O.conv2d(taps["b16/out"], w["head/conv/kernel"], 1), w, "head/bn")).mean(axis=(1, 2)) if hasattr(O, "batchnorm") else None
+    if feat is not None:
+        assert rel_err(got["feat"], feat) < 2e-5
+    assert np.abs(got["logits"] - r["logits"][:5]).max() < 5e-4
+    for head7 in (1, 0):                                   # the fused head conv + pooling kernel and the split-K GEMM + heads kernel
+        hs.set_option("head_fuse", head7)
+        try:
+            g2 = hs.op_head(x)
+        finally:
+            hs.set_option("head_fuse", 1)
+        assert np.abs(g2["logits"] - r["logits"][:5]).max() < 5e-4
+
+
 def test_f32s_batch_invariance_bitwise(hs):
     crops = np.concatenate([synth.scene_crops(40, seed=3), synth.noise_crops(37, seed=4)])
     y, a, l = hs.forward(crops)
