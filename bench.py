@@ -79,7 +79,7 @@ def parse():
                     help="timed steps (default 400: >= 200 ms timed at batch 64)")
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32", "f32s"])
     ap.add_argument("--profile-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -466,9 +466,9 @@ def sweep_leg(blob, local_rank, dev, lanes_opt):
     res = {}
 
     def key_of(nb, dt):
-        return f"b{nb}" if dt == _lib.F16 else f"f32_b{nb}"
+        return f"b{nb}" if dt == _lib.F16 else (f"f32s_b{nb}" if dt == _lib.F32S else f"f32_b{nb}")
 
-    for nb, dt in ((1, _lib.F16), (8, _lib.F16), (512, _lib.F16), (64, _lib.F32)):
+    for nb, dt in ((1, _lib.F16), (8, _lib.F16), (512, _lib.F16), (64, _lib.F32), (64, _lib.F32S)):
         h = _lib.Handle(blob, device=local_rank, dtype=dt)
         if lanes_opt > 0:
             h.set_option("lanes", lanes_opt)
@@ -502,13 +502,16 @@ def sweep_leg(blob, local_rank, dev, lanes_opt):
         _, _, _, _, roof, _ = summarise_profile(stats)
         res[key_of(nb, dt)] = {"value": entry["inflight3"]["crops_s"], "value_serial": entry["serial"]["crops_s"],
                          "ms_per_step": entry["inflight3"]["ms_per_step"], "ms_per_step_serial": entry["serial"]["ms_per_step"],
-                         "steps": entry["inflight3"]["steps"], "dtype": "f16" if dt == _lib.F16 else "f32",
+                         "steps": entry["inflight3"]["steps"], "dtype": {_lib.F16: "f16", _lib.F32: "f32", _lib.F32S: "f32s"}[dt],
                          "dominant_kernel": {"kernel": roof["kernel"], "avg_launch_us": roof["avg_launch_us"],
                                              "crops_per_launch": stats[0]["crops"],
                                              "frac_hbm": roof["frac"], "frac_valu": roof["valu"]["frac"]}}
         h.close()
+    # f32s: parity of THIS run's f32s forward against the float64 oracle on the driver's 16 check crops (the 512-crop contract is
+    # tests/test_f32s.py)
     res["note"] = ("crops resident in HBM; b1 / b8 / b512 = f16, f32_b64 = the parity-grade configuration (1e-3 deg, exact "
-                   "argmax) at the headline batch; value = 3 forwards in flight, value_serial = one at a time; ~0.1 s "
+                   "argmax) at the headline batch, f32s_b64 = the same float32 storage with the 1x1 products as binary16 hi/lo pairs "
+                   "on the f16 matrix cores (WHENET_F32S: same 1e-3 deg bar, tests/test_f32s.py); value = 3 forwards in flight, value_serial = one at a time; ~0.1 s "
                    "timed per schedule (median of 3); dominant kernel from whenet_profile() at that batch (one chain of "
                    "`crops_per_launch` crops)")
     return res
@@ -681,7 +684,7 @@ def main():
     blob = W.pack(W.synthetic(1234)) if rank == 0 else None
     if distributed:
         blob = broadcast_bytes(blob, 0, dev)
-    dt = _lib.F16 if args.dtype == "f16" else _lib.F32
+    dt = {"f16": _lib.F16, "f32": _lib.F32, "f32s": _lib.F32S}[args.dtype]
     h = _lib.Handle(blob, device=local_rank, dtype=dt)
     if args.no_graph:
         h.set_option("graph", 0)
@@ -829,6 +832,17 @@ def main():
                         "north_star_parity_note": ("binary16 activations cannot meet 1e-3 deg / exact argmax (weight rounding alone "
                                                    "moves angles by ~0.3 deg); the f32 configuration does -- sweep.f32_b64 carries its "
                                                    "throughput, latency_b1 its latency") if args.dtype == "f16" else None}
+        if world == 1 and args.dtype == "f16":
+            # the two parity-grade configurations on the SAME check crops (host call, outside every timed region)
+            par = {}
+            for name, pdt in (("f32", _lib.F32), ("f32s", _lib.F32S)):
+                with _lib.Handle(blob, device=local_rank, dtype=pdt) as hp:
+                    y, am, _ = hp.forward(np.ascontiguousarray(crops[idx]))
+                e = np.abs(y - ref_ang)
+                fl = int((am != ref["argmax"]).sum())
+                par[name] = {"max_abs_deg_vs_f64_oracle": float(e.max()), "mean_abs_deg": float(e.mean()), "argmax_flips": fl,
+                             "meets_north_star_parity": bool(e.max() <= 1e-3 and fl == 0)}
+            out["check"]["parity_configurations"] = par
     if rank == 0 and world == 1 and not args.no_latency:
         # configs[1]: batch=1 fp32 latency
         h1 = _lib.Handle(blob, device=local_rank, dtype=_lib.F32)
