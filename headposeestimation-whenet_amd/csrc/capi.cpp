@@ -1,12 +1,15 @@
 // extern "C" surface of libwhenet_hip.so (include/whenet_hip.h).  Every entry point catches
 // everything: no exception crosses the ABI.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <memory>
 #include <new>
+#include <exception>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -27,7 +30,12 @@ struct whenet_ctx {
     // one large BLOCKING call (whenet_forward_u8 with n >= fanout_min) is cut into fanout_chunk-crop forwards spread over the
     // engines through their pinned-slot pipelines: copies of chunk i+1 overlap the forward of chunk i, results are bitwise
     // those of one forward (the kernels are batch-invariant).  fanout_min = 0 switches it off.
-    int fanout_min = 256, fanout_chunk = 64, fanout_stage = 1, fanout_depth = 2;
+    int fanout_min = 256, fanout_chunk = 128, fanout_stage = -1, fanout_depth = 2;
+    // fanout_stage -1 = calibrate: how fast the runtime moves PAGEABLE memory differs from box to box (round 5: the direct form read
+    // 126 k / 90 k / 130 k crops/s on three boxes where pinned staging read 110 / 110 / 107 k), so the first two fan-out calls of
+    // a handle run one form each, time themselves, and the faster one (crops per second) is kept.
+    int fanout_calib_calls = 0;
+    double fanout_calib_rate[2] = {0.0, 0.0};
     std::vector<std::pair<std::string, long>> options;           // replayed on new replicas
     whenet::Engine& at(size_t i) { return i == 0 ? *engine : *replicas[i - 1]; }
     whenet::Engine& take() {
@@ -223,8 +231,9 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
                 WHENET_REQUIRE(value >= 1 && value <= 4096, WHENET_EINVAL, "fanout_chunk must be 1..4096");
                 h->fanout_chunk = int(value);
             } else if (k == "fanout_stage") {
-                WHENET_REQUIRE(value == 0 || value == 1, WHENET_EINVAL, "fanout_stage must be 0 (pinned staging) or 1 (direct)");
+                WHENET_REQUIRE(value >= -1 && value <= 1, WHENET_EINVAL, "fanout_stage must be -1 (calibrate), 0 (pinned staging) or 1 (direct)");
                 h->fanout_stage = int(value);
+                h->fanout_calib_calls = 0;
             } else {
                 WHENET_REQUIRE(value >= 1 && value <= WHENET_MAX_INFLIGHT, WHENET_EINVAL, "fanout_depth must be 1..4");
                 h->fanout_depth = int(value);
@@ -246,33 +255,53 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
             return;
         }
         WHENET_REQUIRE(crops != nullptr && ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
-        // get_angle(np.uint8[N,...]) with a large N (whenet.py:22-27 takes any N): chunks round-robin over the engines,
-        // at most fanout_depth outstanding per engine, collected in submission order into the caller's arrays.
-        struct Pending { whenet::Engine* eng; int ticket, off; };
-        std::vector<Pending> q;
-        size_t head = 0;
-        const size_t depth = size_t(h->inflight) * size_t(h->fanout_depth);
+        // get_angle(np.uint8[N,...]) with a large N (whenet.py:22-27 takes any N): chunk c goes to engine c % inflight, at most
+        // fanout_depth outstanding per engine, results land in the caller's arrays at the chunk's offset.  Every engine is driven
+        // by its OWN host thread (the calling thread takes engine 0): staging a chunk is a 9.6 MB memcpy into pinned memory --
+        // ~0.6 ms on one core, more than the 0.42 ms the GPU needs for the chunk -- so one thread feeding all engines is the
+        // bottleneck (round 5: 105-112 k crops/s at N = 512 whatever the engine count).  Engines share nothing but the device.
+        const int nthreads = h->inflight;
+        const int chunk = h->fanout_chunk, nchunks = (n + chunk - 1) / chunk;
+        int stage = h->fanout_stage;
+        const bool calibrating = stage < 0;
+        if (calibrating) stage = h->fanout_calib_calls < 2 ? 1 - h->fanout_calib_calls : (h->fanout_calib_rate[1] >= h->fanout_calib_rate[0] ? 1 : 0);
+        const auto t_start = std::chrono::steady_clock::now();
         // one engine: the chunk itself supplies the concurrency (two chains); several engines: one chain each
         const int lanes = h->inflight > 1 ? 1 : 2;
-        auto collect_one = [&] {
-            const Pending& p = q[head++];
-            const size_t o = size_t(p.off);
-            p.eng->collect(p.ticket, ypr + o * 3, argmax ? argmax + o * 3 : nullptr, logits ? logits + o * 252 : nullptr);
-        };
-        try {
-            size_t eng_i = 0;
-            for (int off = 0; off < n; off += h->fanout_chunk) {
-                if (q.size() - head >= depth) collect_one();
-                const int cnt = std::min(h->fanout_chunk, n - off);
-                whenet::Engine& eng = h->at(eng_i);
-                eng_i = (eng_i + 1) % size_t(h->inflight);
-                q.push_back(Pending{&eng, eng.submit(crops + size_t(off) * 150528, cnt, h->fanout_stage, lanes), off});
+        std::vector<std::exception_ptr> errs;
+        errs.resize(static_cast<size_t>(nthreads));
+        auto drive = [&](int t) {
+            whenet::Engine& eng = h->at(size_t(t));
+            struct Pending { int ticket, off; };
+            std::vector<Pending> q;
+            size_t head = 0;
+            auto collect_one = [&] {
+                const Pending& p = q[head++];
+                const size_t o = size_t(p.off);
+                eng.collect(p.ticket, ypr + o * 3, argmax ? argmax + o * 3 : nullptr, logits ? logits + o * 252 : nullptr);
+            };
+            try {
+                for (int c = t; c < nchunks; c += nthreads) {
+                    if (q.size() - head >= size_t(h->fanout_depth)) collect_one();
+                    const int off = c * chunk, cnt = std::min(chunk, n - off);
+                    q.push_back(Pending{eng.submit(crops + size_t(off) * 150528, cnt, stage, lanes), off});
+                }
+                while (head < q.size()) collect_one();
+            } catch (...) {
+                errs[size_t(t)] = std::current_exception();
+                eng.abandon_submissions();
             }
-            while (head < q.size()) collect_one();
-        } catch (...) {
-            e.abandon_submissions();
-            for (whenet::Engine* r : h->replicas) r->abandon_submissions();
-            throw;
+        };
+        std::vector<std::thread> workers;
+        for (int t = 1; t < nthreads; ++t) workers.emplace_back(drive, t);
+        drive(0);
+        for (std::thread& w : workers) w.join();
+        for (const std::exception_ptr& ep : errs)
+            if (ep) std::rethrow_exception(ep);
+        if (calibrating && h->fanout_calib_calls < 2) {
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            h->fanout_calib_rate[stage] = double(n) / (sec > 0 ? sec : 1e-9);
+            ++h->fanout_calib_calls;
         }
     });
 }

@@ -19,8 +19,8 @@ Extras that the reference does not have (keyword-only, all optional):
                       get_angle call split contiguously over them (whenet_hip/multi.py), same bits
   dtype='f32'|'f16'|'f32s'   activation / 1x1-weight type (f32 = parity configuration; f32s = float32 storage with the
                       1x1 products as binary16 hi/lo pairs on the f16 matrix cores, include/whenet_hip.h WHENET_F32S)
-  inflight=1..4       engines per handle that one large get_angle call (N >= 256) is spread over in 64-crop chunks, copies
-                      overlapping forwards (include/whenet_hip.h "fanout_min"); default: 2, created at the first such call
+  inflight=1..4       engines per handle that one large get_angle call (N >= 256) is spread over in 128-crop chunks, copies
+                      overlapping forwards, one host thread per engine (include/whenet_hip.h "fanout_min"); default: 2, created at the first such call
   .predict            alias of get_angle (BASELINE.json words the API as WHENet.predict(crop))
   .last_logits, .last_argmax   what Model.predict returned for the last call, and the bin argmax
 """

@@ -143,12 +143,14 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  (f16) / 49 (f32) dependent launches: whenet_info_t.n_kernels_per_forward).  The caller gives every forward in flight its own output
  *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
  *          "fanout_min" (>= 0, default 256: a blocking whenet_forward_u8 of at least this many crops is cut into
- *                  "fanout_chunk"-crop forwards (default 64) that travel through the handle's pinned submission slots,
- *                  round-robin over its "inflight" engines, at most "fanout_depth" (1..4, default 2) outstanding per engine:
- *                  the copy of chunk i+1 overlaps the forward of chunk i.  Results are bitwise those of one forward.
- *                  0 = never.  "fanout_stage": 0 = chunks are copied into pinned staging first, 1 = DMA straight from the
- *                  caller's memory (default; measured round 5 with 2 engines and 64-crop chunks, two boxes: 115 k crops/s at N = 512
- *                  against 105 k for the single forward; 128-crop chunks read 126 k on one box and 90 k on the other)),
+ *                  "fanout_chunk"-crop forwards (default 128); chunk c goes to engine c % inflight through that engine's pinned
+ *                  submission slots, at most "fanout_depth" (1..4, default 2) outstanding per engine, and every engine is driven
+ *                  by its own host thread for the duration of the call (the calling thread takes engine 0): staging a chunk is
+ *                  a 9.6 MB host copy, slower than the GPU's work on it, so the copies of different engines must run in
+ *                  parallel.  Results are bitwise those of one forward.  0 = never.  "fanout_stage": 0 = chunks are copied into
+ *                  pinned staging first, 1 = DMA straight from the caller's pageable memory, -1 (default) = calibrate: the first
+ *                  two fan-out calls of a handle run one form each and the faster is kept (the runtime's pageable path is
+ *                  box-dependent: 126 / 90 / 130 k crops/s direct against 110 / 110 / 107 k staged on three boxes, N = 512)),
  *          "host_pinned_max" (0..4096, default 8: a blocking whenet_forward_u8 of at most this many crops travels through a
  *                  pinned staging slot -- one asynchronous H2D, the forward, three asynchronous D2H, ONE wait -- instead of
  *                  four synchronous copies from / to the caller's pageable memory: the latency path of the reference's
