@@ -46,7 +46,7 @@ from oracle import yolo_oracle as Y  # noqa: E402
 from oracle import preprocess_oracle as P  # noqa: E402
 from tests import refharness as H  # noqa: E402
 
-from tests.refcases import SIZES, FRAMES, YOLO_CASES, crops64, real_valued, boxes_for, all_bytes_image, lut_from_normalised  # noqa: E402
+from tests.refcases import SIZES, FRAMES, YOLO_CASES, crops64, real_valued, boxes_for, all_bytes_image, lut_from_normalised, yolo_case_maps  # noqa: E402
 
 SEED = 1234
 
@@ -130,10 +130,12 @@ def run_yolo():
         with open(os.path.join(R.dir, "yolo_v3", "data", "yolo_anchors.txt")) as f:     # yolo_postprocess.py:62-66
             anchors = np.array([float(x) for x in f.readline().split(",")]).reshape(-1, 2)
         out["anchors"] = anchors.astype(np.float32)
-        for i, (seed, nc, image, max_boxes, score, iou) in enumerate(YOLO_CASES):
-            maps = synth.yolo_maps(seed, num_classes=nc)
+        for i, case in enumerate(YOLO_CASES):
+            seed, nc, image, max_boxes, score, iou = case[:6]
+            maps, case_anchors = yolo_case_maps(case)
+            assert np.array_equal(case_anchors, anchors[:len(case_anchors)].astype(np.float32))
             del R.tf.masked[:]
-            b, s, c = ym.yolo_eval([m[None] for m in maps], anchors, nc, np.array(image), max_boxes=max_boxes,
+            b, s, c = ym.yolo_eval([m[None] for m in maps], anchors[:len(case_anchors)], nc, np.array(image), max_boxes=max_boxes,
                                    score_threshold=score, iou_threshold=iou)
             all_boxes, mask0 = R.tf.masked[0]                       # model.py:219: boolean_mask(boxes, mask[:, 0])
             all_scores = np.stack([R.tf.masked[2 * k + 1][0] for k in range(nc)], axis=1)

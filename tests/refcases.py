@@ -14,7 +14,22 @@ YOLO_CASES = (  # seed, classes, image (h, w), max_boxes, score, iou   (demo_vid
     (1, 1, (720, 1280), 20, 0.3, 0.3),
     (3, 2, (720, 1280), 20, 0.3, 0.45),
     (4, 5, (1080, 607), 20, 0.6, 0.5),
+    (7, 1, (720, 1280), 20, 0.3, 0.45, "tiny"),     # two output maps / six anchors: model.py:203's other anchor mask
+    (9, 1, (1080, 607), 3, 0.3, 0.45, "rect"),      # a 10 x 13 grid (input 320 x 416), max_boxes below the candidate count
 )
+
+
+def yolo_case_maps(case):
+    """The seeded detector maps and anchors of a YOLO_CASES entry."""
+    seed, nc = case[0], case[1]
+    kind = case[6] if len(case) > 6 else ""
+    maps = synth.yolo_maps(seed, num_classes=nc)
+    anchors = synth.YOLO_ANCHORS
+    if kind == "tiny":
+        maps, anchors = maps[:2], anchors[:6]
+    elif kind == "rect":
+        maps = [m[: m.shape[0] // 13 * 10] for m in maps]
+    return maps, anchors
 
 
 def crops64() -> np.ndarray:

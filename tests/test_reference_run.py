@@ -150,23 +150,27 @@ def test_library_windows_equal_process_detection(ref_rects):
 def _yolo_case(ref_yolo, i):
     seed, nc, ih, iw, max_boxes = (int(v) for v in ref_yolo[f"case{i}_cfg"])
     score, iou = (float(v) for v in ref_yolo[f"case{i}_thr"])
-    return synth.yolo_maps(seed, num_classes=nc), nc, (ih, iw), dict(max_boxes=max_boxes, score_threshold=score, iou_threshold=iou)
+    assert (seed, nc, (ih, iw), max_boxes) == (C.YOLO_CASES[i][0], C.YOLO_CASES[i][1], C.YOLO_CASES[i][2], C.YOLO_CASES[i][3])
+    maps, anchors = C.yolo_case_maps(C.YOLO_CASES[i])
+    return maps, anchors, nc, (ih, iw), dict(max_boxes=max_boxes, score_threshold=score, iou_threshold=iou)
 
 
 @pytest.mark.parametrize("i", range(len(C.YOLO_CASES)))
 def test_oracle_yolo_equals_reference_run(ref_yolo, i):
     assert np.array_equal(ref_yolo["anchors"], synth.YOLO_ANCHORS)          # yolo_v3/data/yolo_anchors.txt
-    maps, nc, image, kw = _yolo_case(ref_yolo, i)
-    b, s, c, idx = Y.yolo_eval(maps, synth.YOLO_ANCHORS, nc, image, return_index=True, **kw)
+    maps, anchors, nc, image, kw = _yolo_case(ref_yolo, i)
+    b, s, c, idx = Y.yolo_eval(maps, anchors, nc, image, return_index=True, **kw)
     assert list(c) == list(ref_yolo[f"case{i}_classes"])
     assert np.allclose(s, ref_yolo[f"case{i}_scores"], rtol=1e-6, atol=0)
     assert np.allclose(b, ref_yolo[f"case{i}_boxes"], rtol=1e-6, atol=1e-3)
     # every candidate the reference decoded (model.py:181-190), in yolo_eval's concatenation order
     ab, asc = ref_yolo[f"case{i}_all_boxes"], ref_yolo[f"case{i}_all_scores"]
-    assert ab.shape == (10647, 4) and asc.shape == (10647, nc)
+    n_all = sum(m.shape[0] * m.shape[1] * 3 for m in maps)
+    assert ab.shape == (n_all, 4) and asc.shape == (n_all, nc)
     assert np.allclose(ab[idx], b, rtol=1e-6, atol=1e-3) and np.allclose(asc[idx, c], s, rtol=1e-6)
-    mask = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
-    ob, osc = zip(*[Y.yolo_boxes_and_scores(m, synth.YOLO_ANCHORS[mask[l]], nc, (416, 416), image) for l, m in enumerate(maps)])
+    mask = [[6, 7, 8], [3, 4, 5], [0, 1, 2]] if len(maps) == 3 else [[3, 4, 5], [1, 2, 3]]
+    inp = (maps[0].shape[0] * 32, maps[0].shape[1] * 32)
+    ob, osc = zip(*[Y.yolo_boxes_and_scores(m, anchors[mask[l]], nc, inp, image) for l, m in enumerate(maps)])
     assert np.allclose(np.concatenate(ob), ab, rtol=1e-6, atol=1e-3) and np.allclose(np.concatenate(osc), asc, rtol=1e-6, atol=1e-9)
 
 
@@ -244,10 +248,10 @@ def test_live_process_detection_reproduces_fixture(ref_rects):
 
 @live
 def test_live_yolo_eval_reproduces_fixture(ref_yolo):
-    maps, nc, image, kw = _yolo_case(ref_yolo, 1)
+    maps, anchors, nc, image, kw = _yolo_case(ref_yolo, 1)
     with H.reference(nms_fn=Y.non_max_suppression) as R:
         ym = R.load("yolo_v3.model")
-        b, s, c = ym.yolo_eval([m[None] for m in maps], ref_yolo["anchors"], nc, np.array(image), **kw)
+        b, s, c = ym.yolo_eval([m[None] for m in maps], ref_yolo["anchors"][:len(anchors)], nc, np.array(image), **kw)
     assert np.array_equal(b, ref_yolo["case1_boxes"]) and np.array_equal(s, ref_yolo["case1_scores"])
     assert np.array_equal(c, ref_yolo["case1_classes"])
 
@@ -350,8 +354,8 @@ def test_gpu_frame_windows_equal_process_detection(model_f32, ref_rects):
 @pytest.mark.gpu
 @pytest.mark.parametrize("i", range(len(C.YOLO_CASES)))
 def test_gpu_yolo_equals_reference_run(model_f32, ref_yolo, i):
-    maps, nc, image, kw = _yolo_case(ref_yolo, i)
-    gb, gs, gc, gi, all_boxes, all_scores = model_f32._handle.yolo_eval(maps, synth.YOLO_ANCHORS, nc, image, debug=True, **kw)
+    maps, anchors, nc, image, kw = _yolo_case(ref_yolo, i)
+    gb, gs, gc, gi, all_boxes, all_scores = model_f32._handle.yolo_eval(maps, anchors, nc, image, debug=True, **kw)
     assert np.allclose(all_scores, ref_yolo[f"case{i}_all_scores"], rtol=2e-6, atol=1e-7)
     assert np.allclose(all_boxes, ref_yolo[f"case{i}_all_boxes"], rtol=1e-5, atol=1e-3 * max(image))
     assert list(gc) == list(ref_yolo[f"case{i}_classes"])
