@@ -398,7 +398,7 @@ def yolo_leg(h):
             "note": "blocking whenet_yolo_eval per frame: H2D of the three maps, decode + NMS kernels, D2H"}
 
 
-SWISH_CYCLES_PER_WAVE_VALUE = 24.0      # mul, exp, add, rcp, mul: 3 x 2.6 + 2 x 8.1 cycles per wave-instruction
+SWISH_CYCLES_PER_WAVE_VALUE = 24.0      # mul, exp, add, rcp, mul: 3 x 2.6 + 2 x 8.1 cycles per wave-instruction (docs/experiments.md 3.4)
 SIMDS, SHADER_GHZ = 1024, 2.25
 
 
@@ -444,7 +444,7 @@ def summarise_profile(stats, crops_per_launch=None):
             "tflops": dom["flops"] / (dom["us"] * 1e-6) / 1e12,
             "valu": {"what": "the kernel's Swish activations alone on the 1024 SIMDs: 5 VALU instructions per value, 2 of "
                              "them quarter-rate (v_exp_f32, v_rcp_f32) = 24 cycles per wave-instruction group at 2.25 GHz; "
-                             "this, not HBM, is the binding roof of the fused expand+depthwise kernels (DESIGN.md 3)",
+                             "this, not HBM, is the binding roof of the fused expand+depthwise kernels (DESIGN.md 6.2)",
                      "swish_values_per_launch": dom["swish"] / dom["launches"],
                      "floor_us_per_launch": valu_floor_us / dom["launches"],
                      "frac": (valu_floor_us / dom["us"]) if (dom["us"] > 0 and dom["swish"] > 0) else None,

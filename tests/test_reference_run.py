@@ -320,7 +320,7 @@ def test_gpu_real_valued_input_equals_reference_run(model_f32, crops64, ref_angl
 
 @pytest.mark.gpu
 def test_gpu_f16_against_reference_run(crops64, ref_angles):
-    """the throughput configuration against the reference-run angles: inside the f16 contract (DESIGN: <= 1 deg, mean
+    """the throughput configuration against the reference-run angles: inside the f16 contract (<= 1 deg, mean
     <= 0.12 deg on scene crops), never the 1e-3 bar -- stated, not hidden."""
     import whenet
     with whenet.WHENet(dtype="f16") as m:
