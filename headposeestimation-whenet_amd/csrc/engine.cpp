@@ -242,6 +242,10 @@ void Engine::set_option(const std::string& key, long value) {
         lane_graphs_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "pw_staged") {
+        pw_staged_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "split_pw") {
         WHENET_REQUIRE(split_ || value == 0, WHENET_EINVAL, "split_pw: the handle was not created as WHENET_F32S");
         split_pw_ = value != 0;

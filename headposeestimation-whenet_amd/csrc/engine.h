@@ -135,6 +135,7 @@ class Engine {
     DevPw upload_pw(const HostPw& h);
     // WHENET_F32S: 1x1 products as binary16 hi/lo pairs (option "split_pw" switches the pointwise kernels between the two forms)
     void set_split(PwArgs& a, const DevPw& w) const {
+        a.staged = pw_staged_;
         a.split = split_ && split_pw_ && w.wps != nullptr;
         a.wps = w.wps;
         a.KSs = w.KSs;
@@ -142,6 +143,7 @@ class Engine {
     }
     bool split_ = false;        // the handle was created as WHENET_F32S
     bool split_pw_ = true;      // option "split_pw"
+    bool pw_staged_ = true;     // option "pw_staged": split-K GEMMs fetch their activation rows coalesced, through LDS
     void ensure_capacity(int n);
     void release_arena();
     void drop_graphs();

@@ -107,6 +107,7 @@ struct PwArgs {
     const void* wps = nullptr;     // [hi image | lo image], f16 fragment order (snapshot.cpp::pack_pw_split)
     int KSs = 0;                   // ceil(K / 16)
     float wsi = 1.0f;              // 2^-shift of the scaled weights
+    bool staged = true;            // K >= 320: activation rows fetched coalesced and staged through LDS (whenet_pw_splitk_staged_kernel)
 };
 void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t stream);
 

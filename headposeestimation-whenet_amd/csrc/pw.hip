@@ -40,6 +40,85 @@ namespace whenet {
 
 namespace {
 
+// Combine of the four waves' partial accumulators + bias / activation / skip / store (both split-K kernels): wave p owns a quarter of
+// the accumulators, receives the other three waves' share through LDS and adds them in wave order ((p0 + p1) + p2) + p3.
+template <typename T, int B2, bool RES, int ACT, bool SP>
+__device__ __forceinline__ void splitk_combine_store(float16v (&acc)[B2][B2], float* s_red, int kpart, int lane, int mt, int nt0, int M,
+                                                     int N, int NTILES, const float* __restrict__ bias, const T* __restrict__ res,
+                                                     T* __restrict__ out, float wsi) {
+    using OT = T __attribute__((ext_vector_type(4)));
+    constexpr int MB = B2, NT = B2;
+    constexpr int NACC = MB * NT * 16, SL = NACC / 4;
+    const int g = lane >> 5;
+    // ---- combine: wave p owns accumulators [p*SL, (p+1)*SL) of the flattened (mb, t, r) index -----
+    const int f0 = kpart * SL;                       // first flattened accumulator of this wave's slice
+    const int own_tile = f0 >> 4, own_mb = own_tile / NT, own_t = own_tile % NT;
+    const int own_row = (mt * MB + own_mb) * 32 + (lane & 31);
+    const bool own_valid = own_row < M && nt0 + own_t < NTILES;
+    OT rv[SL / 4];
+    float4v bv[SL / 4];
+#pragma unroll
+    for (int i4 = 0; i4 < SL / 4; ++i4) {            // skip rows and bias of the slice: in flight across the exchange
+        const int qq = ((f0 & 15) >> 2) + i4;
+        const int n0 = (nt0 + own_t) * 32 + 8 * qq + 4 * g;
+        const bool ok = own_valid && n0 < N;
+        bv[i4] = ok ? *reinterpret_cast<const float4v*>(bias + n0) : float4v{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES) rv[i4] = ok ? *reinterpret_cast<const OT*>(res + size_t(own_row) * N + n0) : OT{};
+    }
+    float own[SL];
+#pragma unroll
+    for (int dst = 0; dst < 4; ++dst) {
+        if (dst == kpart) {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int f = dst * SL + i;
+                own[i] = acc[(f >> 4) / NT][(f >> 4) % NT][f & 15];
+            }
+        } else {
+            const int src = (kpart < dst) ? kpart : kpart - 1;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int f = dst * SL + i;
+                s_red[((dst * 3 + src) * SL + i) * 64 + lane] = acc[(f >> 4) / NT][(f >> 4) % NT][f & 15];
+            }
+        }
+    }
+    lds_barrier();
+    STAMP(3);
+    float sum[SL];
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {
+        if (src == kpart) {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) sum[i] = (src == 0) ? own[i] : sum[i] + own[i];
+        } else {
+            const int si = (src < kpart) ? src : src - 1;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const float v = s_red[((kpart * 3 + si) * SL + i) * 64 + lane];
+                sum[i] = (src == 0) ? v : sum[i] + v;
+            }
+        }
+    }
+    if (!own_valid) return;
+#pragma unroll
+    for (int i4 = 0; i4 < SL / 4; ++i4) {
+        const int qq = ((f0 & 15) >> 2) + i4;
+        const int n0 = (nt0 + own_t) * 32 + 8 * qq + 4 * g;
+        if (n0 >= N) continue;
+        OT o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float y = SP ? fmaf(sum[4 * i4 + r], wsi, bv[i4][r]) : sum[4 * i4 + r] + bv[i4][r];
+            if constexpr (ACT == ACT_SWISH) y = conv_swish<T>(y);
+            if constexpr (RES) y += float(rv[i4][r]);
+            o[r] = T(y);
+        }
+        *reinterpret_cast<OT*>(out + size_t(own_row) * N + n0) = o;
+    }
+    STAMP(4);
+}
+
 // Deep contractions (K >= 320: the project convs of blocks 7-16 and the head conv, all on 14x14 / 7x7
 // maps, i.e. few rows).  A workgroup owns B2*32 rows x B2*32 out-channels (B2 x B2 MFMA tiles per wave);
 // its 4 waves split the k-steps interleaved (wave p takes k-steps p, p+4, ..) and the four partial
@@ -188,73 +267,184 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_kernel(
     }
     STAMP(2);
 
-    // ---- combine: wave p owns accumulators [p*SL, (p+1)*SL) of the flattened (mb, t, r) index -----
-    const int f0 = kpart * SL;                       // first flattened accumulator of this wave's slice
-    const int own_tile = f0 >> 4, own_mb = own_tile / NT, own_t = own_tile % NT;
-    const int own_row = (mt * MB + own_mb) * 32 + (lane & 31);
-    const bool own_valid = own_row < M && nt0 + own_t < NTILES;
-    OT rv[SL / 4];
-    float4v bv[SL / 4];
+    splitk_combine_store<T, B2, RES, ACT, SP>(acc, s_red, kpart, lane, mt, nt0, M, N, NTILES, bias, res, out, wsi);
+}
+
+// Round 5: the same product with the activation rows fetched COALESCED and handed to the matrix cores through LDS.
+// Why: a wave's activation fragment is 16 bytes of each of 32 pixel rows (row pitch K x sizeof(T) >= 640 B here): one wave-instruction
+// touches 32 cache lines for 1 KB.  tools/probes/fetch_pattern_probe.hip, 147 workgroups x 147 KB (b13-15's project conv at 64 crops):
+// 27 GB/s per CU with that pattern, 55 GB/s with 8 rows x 128 contiguous bytes per instruction (8 lines per KB) -- the vector cache's
+// line rate, not the L2's bandwidth, was the wall of this kernel (0.13-0.14 of HBM peak, rounds 3-4).  Here
+//   * the K axis is cut into 128-byte GROUPS of a pixel row (f16: 4 k-steps of 16; f32: 4 of 8; f32s: 2 of 16) and wave p owns groups
+//     p, p + 4, ...; a group of the workgroup's MB x 32 rows is MB x 4 wave-instructions of 8 rows x 128 B;
+//   * the loads of the NEXT group travel in registers while the current one is multiplied out of the wave's own 4-8 KB LDS region
+//     (DS operations of a wave execute in order: the stores of group i+1 follow the fragment reads of group i, no barrier);
+//   * slots of 16 B are XOR-swizzled with the row ((r ^ r >> 3) & 7): the coalesced stores and the fragment reads (lane = row j,
+//     piece q) are both bank-conflict free;
+//   * weights (already linear 1 KB per instruction), gate staging, the combine and the epilogue are the kernel's above.
+// Summation order: wave p's partial sum now runs over its k-GROUPS; the combine order is unchanged -- a function of the layer only.
+template <typename T, int B2, int GM, bool RES, int ACT, bool SP = false>
+__global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_staged_kernel(
+    const T* __restrict__ A, const T* __restrict__ Wp, const float* __restrict__ bias, const T* __restrict__ gate,
+    const T* __restrict__ res, T* __restrict__ out, int M, int K, int N, int KS, int NTILES, int HW, int MT, int NCH,
+    const SeFuse se, float wsi) {
+    constexpr bool GATE = GM != 0;
+    using OPS = PwOps<T, SP>;
+    constexpr int V = OPS::V;
+    constexpr int SV = Vec<T>::V;
+    using VT = typename Vec<T>::type;
+    constexpr int MB = B2, NT = B2;
+    constexpr int R = MB * 32;                            // rows of the workgroup's tile
+    constexpr int KSB = 2 * V * int(sizeof(T));           // bytes of a pixel row per k-step: 32 (f16, f32) | 64 (f32s)
+    constexpr int KGS = 128 / KSB;                        // k-steps per 128-byte group
+    constexpr int NLD = R / 8;                            // 16-byte loads per lane and group (8 rows x 128 B per wave-instruction)
+    constexpr int NACC = MB * NT * 16, SL = NACC / 4;
+    constexpr int STAGE_BYTES = 4 * R * 128, RED_BYTES = 4 * 3 * SL * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+    float* s_red = reinterpret_cast<float*>(smem);        // (aliases the staging regions: used after the k-loop, behind a barrier)
+    constexpr int GCROPS = MB + 1, GK = 1152;
+    __shared__ __attribute__((aligned(16))) T s_gate[GATE ? GCROPS * GK : 8];
+    __shared__ float s_r[GM == 2 ? GCROPS * 48 : 4];
+
+    const int id = blockIdx.x;
+    const int q = id >> 3;
+    const int nch = q % NCH;
+    const int mt = (id & 7) + 8 * (q / NCH);
+    if (mt >= MT) return;
+
+    const int lane = threadIdx.x & 63;
+    const int kpart = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt0 = nch * NT;
+    const int g = lane >> 5, j = lane & 31;
+    const int row_first = mt * R;
+    const int crop_lo = row_first / HW;
+    const T* gp[MB];                                      // (LDS) this lane's row of the staged gate, per row block
 #pragma unroll
-    for (int i4 = 0; i4 < SL / 4; ++i4) {            // skip rows and bias of the slice: in flight across the exchange
-        const int qq = ((f0 & 15) >> 2) + i4;
-        const int n0 = (nt0 + own_t) * 32 + 8 * qq + 4 * g;
-        const bool ok = own_valid && n0 < N;
-        bv[i4] = ok ? *reinterpret_cast<const float4v*>(bias + n0) : float4v{0.f, 0.f, 0.f, 0.f};
-        if constexpr (RES) rv[i4] = ok ? *reinterpret_cast<const OT*>(res + size_t(own_row) * N + n0) : OT{};
+    for (int mb = 0; mb < MB; ++mb) {
+        const int row = row_first + mb * 32 + j;
+        const int rowc = row < M ? row : (M - 1);
+        gp[mb] = GATE ? s_gate + (rowc / HW - crop_lo) * K + g * V : nullptr;
     }
-    float own[SL];
+    const int row_last = (row_first + R < M ? row_first + R : M) - 1;
+    const int ncrop = row_last / HW - crop_lo + 1;
+    constexpr int GV = GM == 1 ? (GCROPS * GK / SV + 255) / 256 : 1;
+    VT gv[GV];
+    if constexpr (GM == 1) {
+        const VT* src = reinterpret_cast<const VT*>(gate + size_t(crop_lo) * K);
 #pragma unroll
-    for (int dst = 0; dst < 4; ++dst) {
-        if (dst == kpart) {
-#pragma unroll
-            for (int i = 0; i < SL; ++i) {
-                const int f = dst * SL + i;
-                own[i] = acc[(f >> 4) / NT][(f >> 4) % NT][f & 15];
-            }
-        } else {
-            const int src = (kpart < dst) ? kpart : kpart - 1;
-#pragma unroll
-            for (int i = 0; i < SL; ++i) {
-                const int f = dst * SL + i;
-                s_red[((dst * 3 + src) * SL + i) * 64 + lane] = acc[(f >> 4) / NT][(f >> 4) % NT][f & 15];
-            }
+        for (int jj = 0; jj < GV; ++jj) {
+            const int i = int(threadIdx.x) + jj * 256;
+            gv[jj] = src[i < ncrop * K / SV ? i : 0];
         }
     }
-    lds_barrier();
-    STAMP(3);
-    float sum[SL];
+    const size_t w_lane = size_t(nt0) * 64 + lane;
+    const size_t w_lo = size_t(KS) * NTILES * 64;
+
+    // ---- coalesced source addresses and the swizzled LDS slots ------------------------------------------------------------
+    const int lr = lane >> 3, lq = lane & 7;
+    const int rowbytes = K * int(sizeof(T));
+    const unsigned char* arow[NLD];
+    int woff[NLD];
 #pragma unroll
-    for (int src = 0; src < 4; ++src) {
-        if (src == kpart) {
+    for (int i = 0; i < NLD; ++i) {
+        const int r = i * 8 + lr;
+        const int row = row_first + r;
+        arow[i] = reinterpret_cast<const unsigned char*>(A) + size_t(row < M ? row : M - 1) * rowbytes;
+        woff[i] = r * 128 + ((lq ^ ((r ^ (r >> 3)) & 7)) << 4);
+    }
+    unsigned char* stg = smem + kpart * (R * 128);
+    int rbase[MB], rswz[MB];
 #pragma unroll
-            for (int i = 0; i < SL; ++i) sum[i] = (src == 0) ? own[i] : sum[i] + own[i];
-        } else {
-            const int si = (src < kpart) ? src : src - 1;
+    for (int mb = 0; mb < MB; ++mb) {
+        const int r = mb * 32 + j;
+        rbase[mb] = r * 128;
+        rswz[mb] = (r ^ (r >> 3)) & 7;
+    }
+    const int NG = (KS + KGS - 1) / KGS;
+
+    float16v acc[MB][NT];
 #pragma unroll
-            for (int i = 0; i < SL; ++i) {
-                const float v = s_red[((kpart * 3 + si) * SL + i) * 64 + lane];
-                sum[i] = (src == 0) ? v : sum[i] + v;
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.0f;
+
+    using WF = typename OPS::W;
+    auto issue_a = [&](int gi, VT (&an)[NLD]) {             // (unconditional: clamped group / byte offset, see the kernel above)
+        const int gic = gi < NG ? gi : NG - 1;
+        int off = gic * 128 + lq * 16;
+        off = off < rowbytes - 16 ? off : rowbytes - 16;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) an[i] = *reinterpret_cast<const VT*>(arow[i] + off);
+    };
+    auto issue_w = [&](int gi, WF (&w)[KGS][NT]) {
+#pragma unroll
+        for (int s = 0; s < KGS; ++s) {
+            const int k1 = gi * KGS + s;
+            const int k1c = k1 < KS ? k1 : KS - 1;
+            const size_t wk = w_lane + size_t(k1c) * NTILES * 64;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[s][t] = OPS::load_w(Wp, wk + (nt0 + t < NTILES ? t : 0) * 64, w_lo);
+        }
+    };
+    auto stage = [&](const VT (&an)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<VT*>(stg + woff[i]) = an[i];
+    };
+    auto compute = [&](int gi, const WF (&w)[KGS][NT]) {
+#pragma unroll
+        for (int s = 0; s < KGS; ++s) {
+            const int k1 = gi * KGS + s;
+            if (k1 >= KS) continue;                         // (wave-uniform)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                typename OPS::A a;
+                if constexpr (SP) {
+                    const int q0 = s * 4 + g * 2;
+                    a.x0 = *reinterpret_cast<const float4v*>(stg + rbase[mb] + ((q0 ^ rswz[mb]) << 4));
+                    a.x1 = *reinterpret_cast<const float4v*>(stg + rbase[mb] + (((q0 + 1) ^ rswz[mb]) << 4));
+                } else {
+                    a.v = *reinterpret_cast<const VT*>(stg + rbase[mb] + (((s * 2 + g) ^ rswz[mb]) << 4));
+                }
+                if constexpr (GATE) OPS::gate(a, gp[mb] + k1 * 2 * V);
+                const typename OPS::P pa = OPS::prep(a);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (nt0 + t < NTILES) OPS::step(w[s][t], pa, acc[mb][t]);
             }
         }
-    }
-    if (!own_valid) return;
+    };
+
+    VT an[NLD];
+    WF w0[KGS][NT], w1[KGS][NT];
+    issue_a(kpart, an);
+    issue_w(kpart, w0);
+    if constexpr (GM == 1) {
+        VT* dst = reinterpret_cast<VT*>(s_gate);
 #pragma unroll
-    for (int i4 = 0; i4 < SL / 4; ++i4) {
-        const int qq = ((f0 & 15) >> 2) + i4;
-        const int n0 = (nt0 + own_t) * 32 + 8 * qq + 4 * g;
-        if (n0 >= N) continue;
-        OT o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float y = SP ? fmaf(sum[4 * i4 + r], wsi, bv[i4][r]) : sum[4 * i4 + r] + bv[i4][r];
-            if constexpr (ACT == ACT_SWISH) y = conv_swish<T>(y);
-            if constexpr (RES) y += float(rv[i4][r]);
-            o[r] = T(y);
+        for (int jj = 0; jj < GV; ++jj) {
+            const int i = int(threadIdx.x) + jj * 256;
+            if (i < ncrop * K / SV) dst[i] = gv[jj];
         }
-        *reinterpret_cast<OT*>(out + size_t(own_row) * N + n0) = o;
+        lds_barrier();
     }
-    STAMP(4);
+    if constexpr (GM == 2) se_fused_to_lds<T, 256>(se, crop_lo, ncrop, K, s_gate, s_r);
+    stage(an);
+    for (int gi = kpart; gi < NG; gi += 8) {                // two groups per trip: the weight registers swap roles
+        issue_a(gi + 4, an);
+        issue_w(gi + 4, w1);
+        compute(gi, w0);
+        stage(an);
+        if (gi + 4 < NG) {                                  // (wave-uniform)
+            issue_a(gi + 8, an);
+            issue_w(gi + 8, w0);
+            compute(gi + 4, w1);
+            stage(an);
+        }
+    }
+    lds_barrier();                                          // every wave is done with its staging region: s_red may overwrite it
+    splitk_combine_store<T, B2, RES, ACT, SP>(acc, s_red, kpart, lane, mt, nt0, M, N, NTILES, bias, res, out, wsi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,10 +763,16 @@ PwChoice choose_pw(const PwArgs& a, int num_cus) {
 template <typename T, int B2, int GM, bool RES, int ACT, bool SP>
 void launch_splitk(const PwArgs& a, hipStream_t stream) {
     const int MT = ceil_div(a.M, 32 * B2), NCH = ceil_div(a.NTILES, B2);
-    hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
-                       stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
-                       static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
-                       a.N, SP ? a.KSs : a.KS, a.NTILES, a.HW, MT, NCH, a.se, a.wsi);
+    if (a.staged)
+        hipLaunchKernelGGL((whenet_pw_splitk_staged_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
+                           stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
+                           static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
+                           a.N, SP ? a.KSs : a.KS, a.NTILES, a.HW, MT, NCH, a.se, a.wsi);
+    else
+        hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
+                           stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
+                           static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
+                           a.N, SP ? a.KSs : a.KS, a.NTILES, a.HW, MT, NCH, a.se, a.wsi);
 }
 
 template <typename T, int NT, int GM, bool RES, int ACT, bool SP>
@@ -662,8 +858,8 @@ std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
     } else {
         const PwChoice ch = choose_pw(a, num_cus);
         if (ch.kind == 1)
-            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk_kernel<%s, %d, %s, %s, %d%s>", t,
-                          use_split2(a.M, a.NTILES) ? 2 : 1, gate, res, a.act, a.split ? ", true" : "");
+            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk%s_kernel<%s, %d, %s, %s, %d%s>", a.staged ? "_staged" : "", t,
+                          use_split2(a.M, a.NTILES) ? 2 : 1, gate, res, a.act, a.split ? ", true" : (a.staged ? ", false" : ""));
         else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d%s>", t, ch.NT, gate, res, a.act, a.split ? ", true" : "");
     }
     return buf;
