@@ -730,6 +730,16 @@ __global__ __launch_bounds__(256) void whenet_pw_check_kernel(const T* __restric
 // (>= 128 of them; measured: B=64 +5 %, B=512 +8 %, B <= 16 unchanged)
 bool use_split2(int M, int NTILES) { return ceil_div(M, 64) * ceil_div(NTILES, 2) >= 128; }
 
+// The LDS-staged split-K kernel where it measured faster (round 5, tools/staged_ab.py, one chain of 64 crops, us per launch, direct ->
+// staged): f16 K = 1152: b13-15 13.4 -> 12.7, b16 20.0 -> 14.5; K = 672 on 14 x 14 maps (64 x 64 tiles): 14.2 -> 13.6; K = 480: 12.0 ->
+// 12.3 and K = 672 on 7 x 7 maps: 10.1 -> 11.0 stay direct.  The exact-f32 products are bound by the f32 matrix pipe,
+// not by the fetch: staged is 5-10 % slower there.  A function of the layer (and the handle's dtype) only.
+// (NOT of the batch: the two kernels sum in different orders, and a crop's bits must not depend on the batch it travels in -- so the
+//  tile shape B2, which follows the row count, is not part of the rule.)
+bool use_staged(const PwArgs& a, bool exact_f32) {
+    return a.staged && !exact_f32 && (a.K >= 1152 || (a.K >= 672 && a.HW >= 196));
+}
+
 struct PwChoice {
     int kind;      // 1 = split-K kernel (whenet_pw_kernel<T,1,8,4,..>), 2 = LDS-staged tile kernel
     int NT, NCH;
@@ -763,7 +773,7 @@ PwChoice choose_pw(const PwArgs& a, int num_cus) {
 template <typename T, int B2, int GM, bool RES, int ACT, bool SP>
 void launch_splitk(const PwArgs& a, hipStream_t stream) {
     const int MT = ceil_div(a.M, 32 * B2), NCH = ceil_div(a.NTILES, B2);
-    if (a.staged)
+    if (use_staged(a, IsF32<T>::value && !SP))
         hipLaunchKernelGGL((whenet_pw_splitk_staged_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
                            stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
                            static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
@@ -857,9 +867,12 @@ std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
         std::snprintf(buf, sizeof(buf), "whenet_pw_check_kernel<%s, %s, %s, %d>", t, a.gate ? "true" : "false", res, a.act);
     } else {
         const PwChoice ch = choose_pw(a, num_cus);
-        if (ch.kind == 1)
-            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk%s_kernel<%s, %d, %s, %s, %d%s>", a.staged ? "_staged" : "", t,
-                          use_split2(a.M, a.NTILES) ? 2 : 1, gate, res, a.act, a.split ? ", true" : (a.staged ? ", false" : ""));
+        if (ch.kind == 1) {
+            const int b2 = use_split2(a.M, a.NTILES) ? 2 : 1;
+            const bool st = use_staged(a, dtype == WHENET_F32 && !a.split);
+            std::snprintf(buf, sizeof(buf), "whenet_pw_splitk%s_kernel<%s, %d, %s, %s, %d%s>", st ? "_staged" : "", t, b2, gate, res, a.act,
+                          a.split ? ", true" : (st ? ", false" : ""));
+        }
         else std::snprintf(buf, sizeof(buf), "whenet_pw_tile_kernel<%s, %d, %s, %s, %d%s>", t, ch.NT, gate, res, a.act, a.split ? ", true" : "");
     }
     return buf;

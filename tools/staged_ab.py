@@ -19,17 +19,17 @@ for name in which:
         h.set_option("pw_staged", staged)
         y, a, l = h.forward(host)
         res.setdefault(staged, (y, l))
-        for B in (64, 512):
+        for B in (1, 8, 64, 512):
             crops = torch.randint(0, 256, (B, 224, 224, 3), dtype=torch.uint8, device="cuda")
             outs = [(torch.empty((B, 3), device="cuda"), torch.empty((B, 3), dtype=torch.int32, device="cuda"), torch.empty((B, 252), device="cuda")) for _ in range(3)]
-            for inflight in ((1, 3) if B == 64 else (1,)):
+            for inflight in ((1, 3) if B <= 64 else (1,)):
                 h.set_option("inflight", inflight)
                 def step(i):
                     o = outs[i % inflight]
                     h.forward_device(crops.data_ptr(), B, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
                 for i in range(9): step(i)
                 h.sync()
-                K = 90 if B == 64 else 15
+                K = {1: 300, 8: 200, 64: 90, 512: 15}[B]
                 t0 = time.perf_counter()
                 for i in range(K): step(i)
                 h.sync()
