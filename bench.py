@@ -623,7 +623,7 @@ def pmc_traffic(dtype: str, B: int, crops_per_launch: int, dom_name: str):
     the SAME crops per launch as the profile ran is comparable with `alg_bytes_per_launch`; otherwise traffic is null
     (round 3 printed a 32-crop figure next to 64-crop algorithmic bytes)."""
     tried = []
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", rnd, f"pmc_traffic_{dtype}_b{B}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:

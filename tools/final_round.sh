@@ -2,7 +2,7 @@
 # End-of-round evidence run (on the GPU box): full GPU test suite, default bench, rocprofv3 stats of
 # the SAME bench command, PMC passes for the HBM traffic.  Outputs under gpurun_out/final; copy into profiles/rNN.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-RND=${RND:-r04}
+RND=${RND:-r05}
 mkdir -p $R/gpurun_out/final $R/profiles/$RND
 cd $R
 timeout 900 python -m pytest tests -m gpu -q --tb=short > $R/gpurun_out/final/pytest_gpu.txt 2>&1; echo "pytest exit $?"; tail -3 $R/gpurun_out/final/pytest_gpu.txt
@@ -37,3 +37,19 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 rm -rf $R/gpurun_out/final/rocprof_stats_b512
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats_b512 -o bench -- python $R/bench.py --batch 512 --inflight 1 --no-cpu-baseline --no-latency --no-serial --no-sweep > /dev/null 2>&1; echo "rocprof b512 exit $?"
 cd $R && python tools/gpu_diag.py --quick > $R/gpurun_out/final/diag.txt 2>&1; echo "diag exit $?"
+# ---- round 5 additions: the f32s configuration, counters at 256 crops per launch, the round's A/B and host-path probes
+cd $R
+timeout 300 python bench.py --dtype f32s --no-cpu-baseline --no-latency --no-sweep --dump-layers $R/gpurun_out/final/layers_f32s_b64.json > $R/gpurun_out/final/bench_f32s_b64.json 2>/dev/null; echo "bench f32s exit $?"
+rm -f $R/profiles/$RND/pmc_traffic_f32s_b64.json
+bash tools/pmc_round.sh f32s 64 64 > $R/gpurun_out/final/pmc_f32s_c64.log 2>&1; echo "pmc f32s exit $?"
+python tools/pmc_summary.py gpurun_out/pmc_f32s_b64_c64_p profiles/$RND/pmc_traffic_f32s_b64.json 64 > $R/gpurun_out/final/pmc_f32s_b64_c64_by_kernel.txt 2>&1; echo "pmc f32s summary exit $?"
+rm -f $R/profiles/$RND/pmc_traffic_f16_b512.json
+bash tools/pmc_round.sh f16 512 256 > $R/gpurun_out/final/pmc_c256.log 2>&1; echo "pmc (256 crops per launch) exit $?"
+python tools/pmc_summary.py gpurun_out/pmc_f16_b512_c256_p profiles/$RND/pmc_traffic_f16_b512.json 256 > $R/gpurun_out/final/pmc_f16_b512_c256_by_kernel.txt 2>&1; echo "pmc 256 summary exit $?"
+timeout 300 python tools/staged_ab.py f16 f32s 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $R/gpurun_out/final/staged_splitk_ab.txt; echo "staged ab exit $?"
+timeout 300 python tools/numa_probe.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $R/gpurun_out/final/host_path_numa_probe.txt; echo "numa probe exit $?"
+tools/probes/fetch_pattern_probe > $R/gpurun_out/final/fetch_pattern_probe.txt 2>&1; echo "fetch probe exit $?"
+tools/probes/mfma_denorm_probe > $R/gpurun_out/final/mfma_denorm_probe.txt 2>&1; echo "denorm probe exit $?"
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/final/rocprof_stats_f32s
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/rocprof_stats_f32s -o bench -- python $R/bench.py --dtype f32s --no-cpu-baseline --no-latency --no-serial --no-sweep > /dev/null 2>&1; echo "rocprof f32s exit $?"
