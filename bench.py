@@ -832,7 +832,7 @@ def main():
                         "north_star_parity_note": ("binary16 activations cannot meet 1e-3 deg / exact argmax (weight rounding alone "
                                                    "moves angles by ~0.3 deg); the f32 configuration does -- sweep.f32_b64 carries its "
                                                    "throughput, latency_b1 its latency") if args.dtype == "f16" else None}
-        if world == 1 and args.dtype == "f16":
+        if world == 1 and args.dtype == "f16" and not args.no_sweep:
             # the two parity-grade configurations on the SAME check crops (host call, outside every timed region)
             par = {}
             for name, pdt in (("f32", _lib.F32), ("f32s", _lib.F32S)):
