@@ -857,6 +857,18 @@ def main():
         out["latency_b1"] = {"dtype": "f32", "median_us": float(np.median(lat)), "p99_us": float(np.percentile(lat, 99)),
                              "iters": 1000, "crops_per_s": float(1e6 / np.median(lat))}
         h1.close()
+        # the same single-crop call on the other parity-grade configuration (float32 storage, split products: WHENET_F32S)
+        h1 = _lib.Handle(blob, device=local_rank, dtype=_lib.F32S)
+        lat = []
+        for i in range(600):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            h1.forward_device(d_crops.data_ptr(), 1, d_ypr.data_ptr(), d_am.data_ptr(), d_lg.data_ptr())
+            h1.sync()
+            lat.append(time.perf_counter() - a)
+        lat = np.array(lat[100:]) * 1e6
+        out["latency_b1"]["f32s"] = {"median_us": float(np.median(lat)), "p99_us": float(np.percentile(lat, 99)), "iters": 500}
+        h1.close()
         # configs[4]: one video frame = one submission (host BGR frame + k YOLO boxes -> pinned copy,
         # H2D, crop/resize on the device, forward of the k heads, D2H), PCIe-inclusive, f16
         out["frame_pipeline"] = frame_leg(h)

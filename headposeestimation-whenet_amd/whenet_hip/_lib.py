@@ -10,7 +10,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, F16, F32S = 0, 1, 2          # include/whenet_hip.h WHENET_F32 / WHENET_F16 / WHENET_F32S
 OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EFORMAT, EHIP = 0, -2, -5, -12, -19, -22, -74, -1000
 MAX_INFLIGHT = 4

@@ -35,8 +35,10 @@ extern "C" {
  * 2 (round 3): whenet_op_trunk / whenet_op_stem_dw removed with their kernels; whenet_create_postproc and
  * whenet_op_block_range added; options front_impl, se_fuse, fold12, poison.
  * 3 (round 4): whenet_launch_stat_t carries the crops and chains of the launch it describes (what whenet_profile
- * actually ran: with option "inflight" > 1 a forward is ONE chain of the whole batch). */
-#define WHENET_ABI_VERSION 3
+ * actually ran: with option "inflight" > 1 a forward is ONE chain of the whole batch).
+ * 4 (round 5): dtype WHENET_F32S; whenet_normalise_table; options pw_staged, split_pw, fanout_min / _chunk / _stage / _depth,
+ * host_pinned_max, host_lanes, se_fuse_tiny.  (Additions only: a version-3 caller runs unchanged.) */
+#define WHENET_ABI_VERSION 4
 #define WHENET_API __attribute__((visibility("default")))
 
 /* return codes (negative errno-style) */
@@ -162,6 +164,12 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "repeat" (1..16, default 1, measurement only: the captured graph holds this many back-to-back copies of
  *                  the forward, so that one graph launch times `repeat` forwards without the launch boundary
  *                  between them; results are those of one forward),
+ *          "pw_staged" (0/1, default 1: the K >= 1152 and the 14 x 14 K = 672 project GEMMs of f16 / f32s handles fetch their
+ *                  activation rows coalesced -- 8 rows x 128 contiguous bytes per wave-instruction -- and hand them to the matrix
+ *                  cores through per-wave LDS (whenet_pw_splitk_staged_kernel) instead of loading MFMA fragments (16 bytes of each
+ *                  of 32 rows: 32 cache lines per KB) from global memory; 0 = the direct kernel everywhere.  Another summation
+ *                  order: results agree to rounding.  Chosen by layer, never by batch),
+ *          "split_pw" (0/1, default 1, WHENET_F32S handles only: 0 runs the exact-f32 kernels -- bitwise a WHENET_F32 handle),
  *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
 WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
 
