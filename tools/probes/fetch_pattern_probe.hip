@@ -35,12 +35,18 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ A, float* __re
         }
     } else if (PAT == 1) {
         const int r = lane >> 3, q = lane & 7;
-        for (int kg = p; kg < nline; kg += 4) {
-            float4v v[8];
+        for (int kg = p; kg < nline; kg += 4 * DEPTH) {          // DEPTH groups of 8 loads in flight per wave
+            float4v v[DEPTH][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4v*>(A + size_t(row0 + i * 8 + r) * K2 + kg * 128 + q * 16);
+            for (int d = 0; d < DEPTH; ++d) {
+                int kk = kg + 4 * d; kk = kk < nline ? kk : nline - 1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc += v[i];
+                for (int i = 0; i < 8; ++i) v[d][i] = *reinterpret_cast<const float4v*>(A + size_t(row0 + i * 8 + r) * K2 + kk * 128 + q * 16);
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += v[d][i];
         }
     } else {
         const char* base = A + size_t(row0) * K2;      // 64 rows x K2 bytes as one linear block
@@ -75,9 +81,12 @@ int main() {
     for (int wgs : {49, 147, 256, 512, 1024}) {
         const double bytes = double(wgs) * 64 * K2;
         const double t0 = run<0, 2>(A, out, K2, rows, wgs), t0b = run<0, 4>(A, out, K2, rows, wgs), t1 = run<1, 1>(A, out, K2, rows, wgs), t2 = run<2, 1>(A, out, K2, rows, wgs);
+        const double t1b = run<1, 2>(A, out, K2, rows, wgs), t1c = run<1, 4>(A, out, K2, rows, wgs);
         const int cus = wgs < 256 ? wgs : 256;
-        printf("WGs %4d (147 KB each): fragment pattern %6.2f us (%5.1f GB/s per busy CU), 4 groups deep %6.2f us (%5.1f), coalesced rows %6.2f us (%5.1f), linear %6.2f us (%5.1f)\n",
-               wgs, t0, bytes / t0 / 1e3 / cus, t0b, bytes / t0b / 1e3 / cus, t1, bytes / t1 / 1e3 / cus, t2, bytes / t2 / 1e3 / cus);
+        printf("WGs %4d (147 KB each): fragment pattern %6.2f us (%5.1f GB/s per busy CU), 4 groups deep %6.2f us (%5.1f), coalesced rows %6.2f us (%5.1f), linear %6.2f us (%5.1f)"
+               " | coalesced, 16 / 32 loads in flight per wave: %6.2f us (%5.1f) / %6.2f us (%5.1f)\n",
+               wgs, t0, bytes / t0 / 1e3 / cus, t0b, bytes / t0b / 1e3 / cus, t1, bytes / t1 / 1e3 / cus, t2, bytes / t2 / 1e3 / cus,
+               t1b, bytes / t1b / 1e3 / cus, t1c, bytes / t1c / 1e3 / cus);
     }
     return 0;
 }
