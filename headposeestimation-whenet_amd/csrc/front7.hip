@@ -117,10 +117,50 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
     constexpr bool SPLIT = nstrip * NT <= NWAVE;
     int strip = SPLIT ? (wave < nstrip * NT ? wave % nstrip : nstrip) : wave;
     const int t_lo = SPLIT ? wave / nstrip : 0, t_hi = SPLIT ? t_lo + 1 : NT;
+    // Round 5: a strip's 28 pixels are 28 x Cin x 2 = 10,752 CONTIGUOUS bytes.  Fetched as MFMA fragments (16 bytes of each of 28
+    // pixel rows per lane group) every wave-instruction touches 28 cache lines per KB and a CU pulls ~27 GB/s; fetched as 8 pixels x
+    // 128 contiguous bytes per instruction it pulls ~56 GB/s (tools/probes/fetch_pattern_probe.hip) -- and the activation rows are the
+    // largest thing this workgroup fetches (75 KB of ~130).  So the rows arrive coalesced, 128-byte column groups at a time, and are
+    // turned into fragments through the wave's own 4 KB of the (still unused) tile region: pitch 144 B, conflict-free both ways,
+    // DS operations of a wave execute in order, no barrier.  Pure data movement: the fragments, hence the bits, are the same.
+    // (Groups of 4 crops: 7 strips on 8 waves, 7 x 4,032 B <= the tile region.  Smaller groups keep the direct loads.)
+    constexpr bool STG = !SPLIT && nstrip <= NWAVE && nstrip * 4032 <= (G + 3) / 4 * NCB * ROWS * 64 * 16 && KS % 4 == 0;
     if (strip < nstrip) {
-        const unsigned off = a_offset(strip);
+        if constexpr (STG) {
+            constexpr int PX = 28, SEG = KS / 4;                 // pixels of a strip; 128-byte column groups of a pixel row
+            constexpr int rowb = KS * 32;                        // bytes of a pixel row
+            unsigned char* sa = E + wave * 4032;
+            const size_t last = size_t(p.n) * 49 * rowb - 16;    // (tail groups: any valid address; those crops are never stored)
+            const size_t base = (size_t(crop0) * 49 + size_t(strip) * PX) * rowb;
+            half8 raw[SEG][4];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const half8*>(xb + off + ks * 32);
+            for (int t = 0; t < SEG; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int idx = i * 64 + lane;
+                    idx = idx < PX * 8 ? idx : PX * 8 - 1;
+                    size_t off = base + size_t(idx >> 3) * rowb + t * 128 + (idx & 7) * 16;
+                    off = off < last ? off : last;
+                    raw[t][i] = *reinterpret_cast<const half8*>(xb + off);
+                }
+            int pf = (lm >> 3) * 7 + ((lm & 7) < 7 ? (lm & 7) : 6);      // this lane's pixel of the strip (slot 7: any valid pixel)
+            const int rlim = nrow - strip * 4;                           // image rows of the group left in this strip
+            if ((lm >> 3) >= rlim) pf = (rlim - 1) * 7 + 6;              // (rows past the group: as a_offset clamps them)
+#pragma unroll
+            for (int t = 0; t < SEG; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = i * 64 + lane;
+                    if (idx < PX * 8) *reinterpret_cast<half8*>(sa + (idx >> 3) * 144 + (idx & 7) * 16) = raw[t][i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[t * 4 + u] = *reinterpret_cast<const half8*>(sa + pf * 144 + u * 32 + g * 16);
+            }
+        } else {
+            const unsigned off = a_offset(strip);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const half8*>(xb + off + ks * 32);
+        }
     }
     float bias_t[NT];
 #pragma unroll
@@ -402,7 +442,61 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
     constexpr bool SPLIT = nstrip * NT <= NWAVE;               // (as the f16 kernel: one (strip, tile) task per wave)
     int strip = SPLIT ? (wave < nstrip * NT ? wave % nstrip : nstrip) : wave;
     const int t_lo = SPLIT ? wave / nstrip : 0, t_hi = SPLIT ? t_lo + 1 : NT;
-    if (strip < nstrip) load_rows(a_offset(strip));
+    // Round 5, as the f16 kernel: a strip's 28 pixels are 28 x Cin x 4 contiguous bytes; they arrive as 8 pixels x 128 bytes per
+    // wave-instruction and become fragments through the wave's own 4 KB of the still unused tile region (pitch 144 B).  Same fragments.
+    constexpr bool STG = !SPLIT && nstrip <= NWAVE && KS8 % 4 == 0;
+    if (strip < nstrip) {
+        if constexpr (STG) {
+            constexpr int PX = 28, SEG = KS8 / 4;                // 128-byte column groups of a pixel row (4 k-steps of 8 each)
+            constexpr int rowb = KS8 * 32;
+            unsigned char* sa = E + wave * 4032;
+            const size_t last = size_t(p.n) * 49 * rowb - 16;
+            const size_t base = (size_t(crop0) * 49 + size_t(strip) * PX) * rowb;
+            int pf = (lm >> 3) * 7 + ((lm & 7) < 7 ? (lm & 7) : 6);
+            const int rlim = nrow - strip * 4;
+            if ((lm >> 3) >= rlim) pf = (rlim - 1) * 7 + 6;
+            OPS::A rawsp[SP ? KS16 : 1];
+#pragma unroll
+            for (int t0 = 0; t0 < SEG; t0 += 3) {                // three column groups in flight (12 registers)
+                float4v raw[3][4];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int idx = i * 64 + lane;
+                        idx = idx < PX * 8 ? idx : PX * 8 - 1;
+                        size_t off = base + size_t(idx >> 3) * rowb + (t0 + tt) * 128 + (idx & 7) * 16;
+                        off = off < last ? off : last;
+                        raw[tt][i] = *reinterpret_cast<const float4v*>(xb + off);
+                    }
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) {
+                    const int t = t0 + tt;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = i * 64 + lane;
+                        if (idx < PX * 8) *reinterpret_cast<float4v*>(sa + (idx >> 3) * 144 + (idx & 7) * 16) = raw[tt][i];
+                    }
+                    if constexpr (SP) {                          // a 128-byte group = 2 k-steps of 16: 32 B per lane and k-step
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            rawsp[t * 2 + u].x0 = *reinterpret_cast<const float4v*>(sa + pf * 144 + u * 64 + g * 32);
+                            rawsp[t * 2 + u].x1 = *reinterpret_cast<const float4v*>(sa + pf * 144 + u * 64 + g * 32 + 16);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a[t * 4 + u] = *reinterpret_cast<const float4v*>(sa + pf * 144 + u * 32 + g * 16);
+                    }
+                }
+            }
+            if constexpr (SP) {
+#pragma unroll
+                for (int ks = 0; ks < KS16; ++ks) ap[ks] = OPS::prep(rawsp[ks]);
+            }
+        } else {
+            load_rows(a_offset(strip));
+        }
+    }
     float bias_t[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias_t[t] = p.be[c0 + t * 32 + lm];
