@@ -416,10 +416,10 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
     r.se_ntiles = r.use_f7 ? 1 : (r.use_f2 ? b.f2plan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles()));
     r.se_chunks = r.use_f7 ? b.f7_chunks : (r.use_f2 ? b.f2plan.chunks : b.fplan.chunks);
     const bool se_pays = b.project.K < 320 && r.se_ntiles * r.se_chunks <= 24;
-    // option "se_fuse_tiny" (default 0 = off): chains of at most that many crops fuse every block's gate.  Round 4 read +3 % at
-    // B=1 for se_fuse=2 on device-resident input; round 5 measured the host call (get_angle(uint8[1,...])) the other way
-    // round -- 490 us fused against 461 us with the 13 excite launches (f32), 379 against 353 (f16) -- so it stays off.
-    const bool tiny = !single_stage_call_ && n > 0 && n <= se_fuse_tiny_;
+    // option "se_fuse_tiny": chains of at most that many crops are launch-bound (B=1: 46-49 launches x ~8 us), so every launch
+    // saved pays -- EXCEPT on the 7 x 7 blocks (K = 1152), whose project workgroups would each pull the whole 221 KB excite
+    // kernel: se_fuse=2 on all blocks measured 451 us against 420 us at B=1 (round 5).  Blocks 2-12 fuse; same bits either way.
+    const bool tiny = !single_stage_call_ && n > 0 && n <= se_fuse_tiny_ && b.project.K < 1152;
     r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && (se_pays || tiny)));
     return r;
 }
