@@ -134,3 +134,24 @@ def test_f32s_dropin_class():
     with whenet.WHENet(dtype="f32s") as m:
         y, p, r = m.get_angle(C.crops64()[:9])
     assert np.abs(np.stack([y, p, r], 1) - ref["n9_angles"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32s"])
+def test_staged_splitk_option(blob, dtype):
+    """Option pw_staged (round 5): the K >= 1152 / 14x14 K = 672 project GEMMs fetch their activation rows coalesced through per-wave
+    LDS.  Another summation order than the direct kernel (wave p sums 128-byte k-groups instead of interleaved k-steps): results
+    agree to rounding, each form is bitwise batch-invariant on its own, and the choice never depends on the batch."""
+    dt = {"f16": _lib.F16, "f32s": _lib.F32S}[dtype]
+    crops = np.concatenate([synth.scene_crops(30, seed=8), synth.noise_crops(27, seed=9)])
+    outs = {}
+    with _lib.Handle(blob, device=0, dtype=dt) as h:
+        for staged in (1, 0):
+            h.set_option("pw_staged", staged)
+            y, a, l = h.forward(crops)
+            for n in (1, 3, 20, 21):                      # both tile shapes of the split-K kernels (B2 = 1 below 21 crops on 14x14)
+                yn, an, ln = h.forward(crops[:n])
+                assert np.array_equal(yn, y[:n]) and np.array_equal(ln, l[:n]), (staged, n)
+            outs[staged] = (y, l)
+    tol = 0.2 if dtype == "f16" else 2e-4
+    assert np.abs(outs[0][0] - outs[1][0]).max() < tol
+    assert not np.array_equal(outs[0][1], outs[1][1]), "pw_staged did not change the kernel"
