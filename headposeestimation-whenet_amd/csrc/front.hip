@@ -220,12 +220,14 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     constexpr int W1V = 16;
     const int fj = tid >> 2, fq = tid & 3;
     float w1v[W1V];
-    {
+#pragma unroll
+    for (int i = 0; i < W1V; ++i) w1v[i] = 0.f;
+    if (w1t != nullptr && __builtin_amdgcn_readfirstlane(wave) * 16 < R) {      // (wave-uniform: waves without an output fj < R skip the loads)
         const float* wrow = w1t + size_t(fj < R ? fj : 0) * Cexp + c0;
 #pragma unroll
         for (int i = 0; i < W1V; ++i) {
             const int c = fq + 4 * i;
-            w1v[i] = (w1t != nullptr && fj < R && c < ccur) ? wrow[c] : 0.f;
+            w1v[i] = (fj < R && c < ccur) ? wrow[c] : 0.f;
         }
     }
     lds_barrier();

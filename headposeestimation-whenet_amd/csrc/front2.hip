@@ -359,7 +359,9 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         const int jo = tid >> 2, q = tid & 3;
 #pragma unroll
         for (int i = 0; i < W1V; ++i) w1v[i] = 0.f;
-        if (p.w1t != nullptr) {                                // (uniform; clamped addresses: no lane predicates)
+        // (only the waves that hold an output jo < RPse need them -- block 2: R = 4, i.e. 16 lanes of wave 0; the other seven
+        //  waves used to issue the same 16 strided loads and ~70 address instructions for nothing: round 5)
+        if (p.w1t != nullptr && wave * 16 < p.RPse) {          // (uniform; clamped addresses: no lane predicates)
             const float* wrow = p.w1t + size_t(jo < p.R ? jo : p.R - 1) * p.Cexp + c0;
 #pragma unroll
             for (int i = 0; i < W1V; ++i) {
