@@ -160,6 +160,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     constexpr int D = WHENET_F2_RING;
     half8 w[KS], aq[D][PF];
     float bias_cur = 0.f;
+    float16v bias16;                                           // splat of bias_cur, refreshed by load_w (see the task loop)
     // The folded block-1 project (engine.cpp, option fold12): the expand's input is the PREVIOUS block's gated
     // depthwise output; the gate scales the contraction index, so it is applied to this crop's copy of the weights
     // instead of to every pixel row -- in f32 (f32 composed weights x f32 gate, ONE rounding to f16 per weight; the
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         }
         const int ch = tl * 32 + lm;
         bias_cur = (ch < ccur) ? p.be[c0 + ch] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias16[r] = bias_cur;
     };
     // k beyond Cin (Cin = 24 / 40: the upper half of the last k-step): the packed weights are zero there, but the 16
     // bytes past a pixel row are the next pixel's channels -- or, for the last pixel of the last crop, whatever follows
@@ -259,12 +262,14 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
       for (int d = 0; d < D; ++d) {
         const int t = t0 + d;
         if (t >= t_end) break;                                 // (uniform)
+        // (this lane's channel: BN bias as the accumulators' initial value.  Round 5: the 16-register splat of the bias is kept in
+        //  its OWN registers and handed to the first MFMA as the C operand with another destination -- written as `acc[r] =
+        //  bias` in front of every task the compiler spent 23 v_mov per task on it, a fifth of the task's VALU instructions)
         float16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias_cur;        // (this lane's channel: BN bias as the initial value)
         zero_ktail(aq[d], 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][0], w[0], bias16, 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[u], acc, 0, 0, 0);
+        for (int u = 1; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[d][u], w[u], acc, 0, 0, 0);
 #pragma unroll
         for (int ks = PF; ks < KS; ks += PF) {
             load_a(aq[d], aoffq[d], ks);
@@ -385,8 +390,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
         const int c = cb * 16 + cl;
         const unsigned char* bp = E + c * CP + ((c >> 3) & 1) * 8 + (seg * RL * S) * RP + xgl * (8 * S);
         float4v acc[RL];
+        const float4v bd4 = float4v{bdv, bdv, bdv, bdv};       // (BN bias as the initial value: the C operand of a row's FIRST product --
+        bool started[RL];                                      //  everything here unrolls, the flags fold at compile time)
 #pragma unroll
-        for (int r = 0; r < RL; ++r) acc[r] = float4v{bdv, bdv, bdv, bdv};          // (BN bias as the initial value)
+        for (int r = 0; r < RL; ++r) started[r] = false;
 #pragma unroll
         for (int er = 0; er < NER; ++er) {
             half4 bv[NCH];
@@ -397,8 +404,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
                 const int d = er - ky;
                 if (d >= 0 && d % S == 0 && d / S < RL) {
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch)
-                        acc[d / S] = __builtin_amdgcn_mfma_f32_4x4x4f16(A[ky][ch], bv[ch], acc[d / S], 0, 0, 0);
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        acc[d / S] = __builtin_amdgcn_mfma_f32_4x4x4f16(A[ky][ch], bv[ch], started[d / S] ? acc[d / S] : bd4, 0, 0, 0);
+                        started[d / S] = true;
+                    }
                 }
             }
         }
