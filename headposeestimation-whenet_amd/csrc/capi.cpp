@@ -293,8 +293,14 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
             }
         };
         std::vector<std::thread> workers;
-        for (int t = 1; t < nthreads; ++t) workers.emplace_back(drive, t);
+        workers.reserve(size_t(nthreads));
+        int started = 1;                                         // (engine 0 is the calling thread's)
+        try {
+            for (int t = 1; t < nthreads; ++t, ++started) workers.emplace_back(drive, t);
+        } catch (...) {                                          // no thread to be had: the engines without one are driven from here
+        }
         drive(0);
+        for (int t = started; t < nthreads; ++t) drive(t);
         for (std::thread& w : workers) w.join();
         for (const std::exception_ptr& ep : errs)
             if (ep) std::rethrow_exception(ep);

@@ -274,6 +274,7 @@ class Cv2Recorder(types.ModuleType):
     putText = _record("putText")
     imshow = _record("imshow")
     waitKey = _record("waitKey")
+    del _record
 
 
 class RecordingFrame:
