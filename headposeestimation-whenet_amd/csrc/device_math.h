@@ -136,6 +136,7 @@ template <typename T, bool SP> struct PwOps {
     static __device__ __forceinline__ A load_a(const T* p) { return A{*reinterpret_cast<const VT*>(p)}; }
     static __device__ __forceinline__ A zero_a() { return A{vec_zero<T>()}; }
     static __device__ __forceinline__ void gate(A& a, const T* g) { a.v = a.v * *reinterpret_cast<const VT*>(g); }
+    static __device__ __forceinline__ void gate_by(A& a, const A& g) { a.v = a.v * g.v; }
     static __device__ __forceinline__ P prep(const A& a) { return P{a.v}; }
     // w: the layer's packed image; i: index of the lane's 16-byte fragment in it; lo_off: unused
     static __device__ __forceinline__ W load_w(const T* w, size_t i, size_t) { return W{reinterpret_cast<const VT*>(w)[i]}; }
@@ -154,6 +155,10 @@ template <> struct PwOps<float, true> {
     static __device__ __forceinline__ void gate(A& a, const float* g) {
         a.x0 = a.x0 * *reinterpret_cast<const float4v*>(g);
         a.x1 = a.x1 * *reinterpret_cast<const float4v*>(g + 4);
+    }
+    static __device__ __forceinline__ void gate_by(A& a, const A& g) {
+        a.x0 = a.x0 * g.x0;
+        a.x1 = a.x1 * g.x1;
     }
     static __device__ __forceinline__ P prep(const A& a) {
         P p;

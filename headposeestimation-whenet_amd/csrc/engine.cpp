@@ -97,6 +97,15 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype)
                 partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f2plan.ntiles()) * size_t(b.f2plan.chunks) *
                                                                     size_t(se_padded_r(b.se.R)));
             }
+            if (split_ && front2s_supported(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.cin)) {
+                // f32s: the same stage with both convolutions on the matrix cores (front2s.hip, round 6)
+                b.f2s_supported = true;
+                b.f2splan = plan_front2s(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.h_out, hb.dw.C, &b.f2s_tm);
+                b.f2s_preferred = front2s_preferred(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.dw.C);
+                b.dw.wts = upload(pack_dw_toeplitz_s(hb.dw.w, hb.spec.k, hb.spec.s, hb.dw.C, b.f2s_tm, &b.dw.wts_wsi));
+                partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f2splan.ntiles()) * size_t(b.f2splan.chunks) *
+                                                                    size_t(se_padded_r(b.se.R)));
+            }
             // the 7 x 7 blocks, both dtypes: a group of crops per workgroup (front7.hip); f16: its Toeplitz image is group-aligned
             b.f7_supported = front7_supported(hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.cin);
             if (b.f7_supported) {
@@ -204,8 +213,14 @@ void Engine::set_option(const std::string& key, long value) {
         drop_graphs();
     } else if (key == "front_impl") {
         WHENET_REQUIRE(value >= 0 && value <= 2, WHENET_EINVAL,
-                       "front_impl must be 0 (front.hip everywhere), 1 (per layer, default) or 2 (front2.hip everywhere, f16)");
+                       "front_impl must be 0 (front.hip everywhere), 1 (per layer, default) or 2 (front2.hip / front2s.hip wherever they exist)");
         front_impl_ = int(value);
+        sync();
+        drop_graphs();
+    } else if (key == "f2s_mask") {
+        // probes: bit i set = block i runs front2s.hip (f32s handles, front_impl = 1); -1 = the measured per-layer table
+        WHENET_REQUIRE(value >= -1 && value < (1 << 17), WHENET_EINVAL, "f2s_mask must be -1 or a bit mask of blocks 2..12");
+        f2s_mask_ = int(value);
         sync();
         drop_graphs();
     } else if (key == "head_fuse") {
@@ -412,9 +427,12 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
     r.fused = fuse_front_ && b.spec.has_expand() && pw_impl_ == 0;
     r.use_f7 = r.fused && front_impl_ == 1 && front7_ && b.f7_supported;
     r.use_f2 = r.fused && !r.use_f7 && dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
+    const bool f2s_pick = f2s_mask_ >= 0 ? ((f2s_mask_ >> b.spec.index) & 1) != 0 : b.f2s_preferred;     // (option "f2s_mask": probes)
+    r.use_f2s = r.fused && !r.use_f7 && split_ && split_pw_ && b.f2s_supported && b.expand.wps != nullptr &&
+                (front_impl_ == 2 || (front_impl_ == 1 && f2s_pick));
     r.se_in_front = r.fused;                 // the front kernels apply the SE reduce conv to their channel sums
-    r.se_ntiles = r.use_f7 ? 1 : (r.use_f2 ? b.f2plan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles()));
-    r.se_chunks = r.use_f7 ? b.f7_chunks : (r.use_f2 ? b.f2plan.chunks : b.fplan.chunks);
+    r.se_ntiles = r.use_f7 ? 1 : (r.use_f2 ? b.f2plan.ntiles() : (r.use_f2s ? b.f2splan.ntiles() : (r.fused ? b.fplan.ntiles() : b.dw.plan.ntiles())));
+    r.se_chunks = r.use_f7 ? b.f7_chunks : (r.use_f2 ? b.f2plan.chunks : (r.use_f2s ? b.f2splan.chunks : b.fplan.chunks));
     const bool se_pays = b.project.K < 320 && r.se_ntiles * r.se_chunks <= 24;
     // option "se_fuse_tiny": chains of at most that many crops are launch-bound (B=1: 46-49 launches x ~8 us), so every launch
     // saved pays -- EXCEPT on the 7 x 7 blocks (K = 1152), whose project workgroups would each pull the whole 221 KB excite
@@ -425,8 +443,12 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
 }
 
 bool Engine::fold12_active() const {
-    return fold12_ && dtype_ == WHENET_F16 && fuse_front_ && pw_impl_ == 0 && blocks_.size() >= 2 &&
-           (front_impl_ == 2 || (front_impl_ == 1 && blocks_[1].f2_preferred));
+    if (!(fold12_ && fuse_front_ && pw_impl_ == 0 && blocks_.size() >= 2)) return false;
+    if (dtype_ == WHENET_F16) return front_impl_ == 2 || (front_impl_ == 1 && blocks_[1].f2_preferred);
+    // f32s (round 6): front.hip's split form takes the gate on its float32 operand; the exact-f32 form does not fold (its expand is
+    // matrix-pipe bound: doubling the contraction costs more than block 1's project launch saves)
+    const BlockSchedule b2 = block_schedule(blocks_[1]);
+    return split_ && split_pw_ && fold12_pw_.wps != nullptr && b2.fused && !b2.use_f2s && !b2.use_f7;
 }
 
 // The stem's output is read by block 1's depthwise conv only (block 1 has no expand conv and no skip): for handles fed
@@ -462,7 +484,8 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     const bool fused = bs.fused, use_f2 = bs.use_f2, se_in_front = bs.se_in_front, se_fused = bs.se_fused;
     const int se_ntiles = bs.se_ntiles, se_chunks = bs.se_chunks;
     // (checked before anything is enqueued: a violated invariant must not leave half a block in a stream capture)
-    WHENET_REQUIRE(fold == 0 || (fold == 1 && !fused && sp.index == 1) || (fold == 2 && use_f2 && sp.index == 2), WHENET_EINVAL,
+    WHENET_REQUIRE(fold == 0 || (fold == 1 && !fused && sp.index == 1) ||
+                       (fold == 2 && sp.index == 2 && (use_f2 || (split_ && fused && !bs.use_f2s && !bs.use_f7))), WHENET_EINVAL,
                    "fold12: block outside the folded pair");
     if (bs.use_f7) {
         Front7Args a{};
@@ -521,6 +544,34 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         R(p + "/front", "front", kernel_name_front2(sp.k, sp.s, a.KSe, a.plan.threads, a.plan.xs, a.in_gate != nullptr).c_str(),
           double(n) * (hw_in * a.Cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * a.Cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front2(a, s); });
+    } else if (bs.use_f2s) {
+        Front2sArgs a{};
+        a.x = in;
+        a.weps = b.expand.wps;
+        a.be = b.expand.bias;
+        a.wdt = b.dw.wts;
+        a.bd = b.dw.bias;
+        a.out = v.d;
+        a.rpart = v.partial;
+        a.w1t = b.se.w1t;                    // the SE reduce conv is applied by the front kernel to its channel sums
+        a.R = b.se.R;
+        a.k = sp.k;
+        a.s = sp.s;
+        a.H = sp.h_in;
+        a.Ho = sp.h_out;
+        a.Cin = sp.cin;
+        a.Cexp = cexp;
+        a.pad = sp.pad_before();
+        a.KSe = b.expand.KSs;
+        a.NTe = b.expand.NTILES;
+        a.wsi = b.expand.wsi;
+        a.wsi_d = b.dw.wts_wsi;
+        a.tm = b.f2s_tm;
+        a.n = n;
+        a.plan = b.f2splan;
+        R(p + "/front", "front", kernel_name_front2s(sp.k, sp.s, a.KSe, a.plan.threads, a.tm, false).c_str(),
+          double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
+          2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front2s(a, s); });
     } else if (fused) {
         FrontArgs a{};
         a.x = in;
@@ -545,11 +596,21 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.weps = b.expand.wps;
         a.KSes = b.expand.KSs;
         a.wsi = b.expand.wsi;
+        if (fold == 2) {                     // input = block 1's depthwise output, gated; weights = project1 x expand2 (f32s)
+            a.weps = fold12_pw_.wps;
+            a.be = fold12_pw_.bias;
+            a.Cin = fold12_pw_.K;
+            a.KSe = fold12_pw_.KS;
+            a.KSes = fold12_pw_.KSs;
+            a.NTe = fold12_pw_.NTILES;
+            a.wsi = fold12_pw_.wsi;
+            a.in_gate = static_cast<const float*>(v.gate);
+        }
         a.n = n;
         a.plan = b.fplan;
         a.plan.threads = front_threads(b.fplan, n);
-        R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s, a.plan.threads).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
-          2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
+        R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s, a.plan.threads).c_str(), double(n) * (hw_in * a.Cin + hw_out * cexp) * es,
+          2.0 * n * (double(hw_in) * a.Cin * cexp + double(hw_out) * sp.k * sp.k * cexp),
           [&] { launch_front(a, dtype_, s); });
     } else if (sp.has_expand()) {
         PwArgs a{};

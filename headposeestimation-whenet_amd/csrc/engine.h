@@ -30,6 +30,8 @@ struct DevDw {
     float* bias = nullptr;
     half_t* wt = nullptr;      // f16: Toeplitz operand image of the kernel for front2.hip (pack_dw_toeplitz)
     half_t* wt7 = nullptr;     // f16, 7 x 7 blocks: the image front7.hip reads (group-aligned: xs = 4 - k / 2)
+    float* wts = nullptr;      // WHENET_F32S: Toeplitz operand image for front2s.hip in the block's tap mode (pack_dw_toeplitz_s)
+    float wts_wsi = 1.0f;      //   2^-shift of its scaled taps (tap mode 1)
     DwPlan plan;
 };
 struct DevSe {
@@ -44,6 +46,9 @@ struct DevBlock {
     FrontPlan fplan;       // fused expand+depthwise tiling (blocks with an expand conv)
     Front2Plan f2plan;     // f16: the same stage with the taps on the matrix cores (front2.hip)
     bool f2_preferred = false;
+    Front2Plan f2splan;    // WHENET_F32S: front2s.hip's plan, tap mode, and whether it is the faster kernel on this layer
+    int f2s_tm = 2;
+    bool f2s_supported = false, f2s_preferred = false;
     bool f7_supported = false; // f16: the block's shape has a front7.hip kernel (7 x 7 maps, blocks 13-16)
     int f7_chunks = 1;         // channel chunks of its plans (the same for every group size: see front7_plan_for)
     DevSe se;
@@ -168,12 +173,13 @@ class Engine {
     bool stem_fuse_active() const;
     bool fold12_active() const;
     struct BlockSchedule {     // which kernels a block runs under the current options
-        bool fused = false, use_f2 = false, use_f7 = false, se_in_front = false, se_fused = false;
+        bool fused = false, use_f2 = false, use_f2s = false, use_f7 = false, se_in_front = false, se_fused = false;
         int se_ntiles = 1, se_chunks = 1;
     };
     // n = crops of the chain the block runs in (0: not batch-specific, e.g. the launch count of get_info)
     BlockSchedule block_schedule(const DevBlock& b, int n = 0) const;
     int se_fuse_tiny_ = 0;             // option "se_fuse_tiny"
+    int f2s_mask_ = -1;                // option "f2s_mask" (probes)
     bool single_stage_call_ = false;   // op_block / op_block_range: the schedule must not depend on the test's batch size
     int lanes_for(int n, int want) const;     // chains a forward of n crops runs as (want = 0: option "lanes")
     void enqueue_lanes(const uint8_t* d_in, int n, float* d_ypr, int32_t* d_amax, float* d_logits, hipStream_t s, int want = 0);

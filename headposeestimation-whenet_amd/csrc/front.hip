@@ -44,7 +44,7 @@ constexpr int VC = 4;
 // this kernel used to spend a third of its VALU cycles in them.
 __device__ __forceinline__ int fdiv(int q, float rinv) { return int((float(q) + 0.5f) * rinv); }
 
-template <typename T, int K, int S, int NTHR, bool SP = false>
+template <typename T, int K, int S, int NTHR, bool SP = false, bool GATED = false>
 __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restrict__ x, const T* __restrict__ wep,
                                                             const float* __restrict__ be,
                                                             const float* __restrict__ wd,
@@ -52,7 +52,10 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                                                             float* __restrict__ rpart, int H, int Ho, int Cin,
                                                             int Cexp, int pad, int KSe, int NTe, int CC, int TH,
                                                             int NSX, int tiles_x, int EH, int EW, int EP, int w_off,
-                                                            const float* __restrict__ w1t, int R, int RP, float wsi) {
+                                                            const float* __restrict__ w1t, int R, int RP, float wsi,
+                                                            const float* __restrict__ in_gate) {
+    // GATED (SP only, round 6): the expand contracts (in_gate[crop] * x) -- block 2 fed by block 1's depthwise output with block 1's
+    // project folded into the expand weights (engine.cpp, option fold12); the gate multiplies the float32 operand before it is split.
     // SP (T = float, WHENET_F32S): the expand products as binary16 hi/lo pairs on the f16 matrix cores (device_math.h PwOps);
     // KSe then counts 16-deep k-steps and wep is the [hi | lo] image pair.  Everything behind the expand is unchanged.
     using OPS = PwOps<T, SP>;
@@ -177,7 +180,16 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     lds_barrier();
     STAMP(1);
 
+    AF gq[PF];                                 // GATED: the crop's gate in the operand fragments' layout (Cin <= 2 V PF: one group of k-steps)
+    if constexpr (GATED) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) gq[u] = (u * 2 * V + g * V < Cin) ? OPS::load_a(reinterpret_cast<const T*>(in_gate) + size_t(b) * Cin + u * 2 * V + g * V) : OPS::zero_a();
+    }
     for (int t = wave; t < ntask; t += NWAVE) {
+        if constexpr (GATED) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) OPS::gate_by(a[u], gq[u]);
+        }
         float16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     STAMP(6);
 }
 
-template <typename T, int K, int S, int NTHR, bool SP = false>
+template <typename T, int K, int S, int NTHR, bool SP = false, bool GATED = false>
 void launch_t(const FrontArgs& a, hipStream_t stream) {
     const FrontPlan& p = a.plan;
     dim3 grid(p.tiles_x * p.tiles_y, p.chunks, a.n);
@@ -352,19 +364,25 @@ void launch_t(const FrontArgs& a, hipStream_t stream) {
     int dev = 0;
     WHENET_HIP_CHECK(hipGetDevice(&dev));
     if (p.lds_bytes > 64 * 1024 && dev >= 0 && dev < 64 && !attr[dev].load(std::memory_order_acquire)) {
-        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S, NTHR, SP>),
+        WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(whenet_front_kernel<T, K, S, NTHR, SP, GATED>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR, SP>), grid, dim3(NTHR), p.lds_bytes, stream,
+    hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR, SP, GATED>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(SP ? a.weps : a.wep), a.be, a.wd, a.bd,
                        static_cast<T*>(a.out), a.rpart, a.H, a.Ho, a.Cin, a.Cexp, a.pad, SP ? a.KSes : a.KSe, a.NTe, p.CC, p.TH, p.NSX,
-                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3, a.wsi);
+                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3, a.wsi, a.in_gate);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
 template <typename T, int NTHR, bool SP = false>
 void launch_ks(const FrontArgs& a, hipStream_t stream) {
+    if constexpr (SP) {
+        if (a.in_gate != nullptr) {                 // block 2 with block 1's project folded in (the only gated shape)
+            WHENET_REQUIRE(a.k == 3 && a.s == 2 && a.Cin == 32 && a.KSes == 2, WHENET_EINVAL, "front: the gated-input form exists for block 2's shape only");
+            return launch_t<T, 3, 2, NTHR, true, true>(a, stream);
+        }
+    }
     if (a.k == 3 && a.s == 1) launch_t<T, 3, 1, NTHR, SP>(a, stream);
     else if (a.k == 3 && a.s == 2) launch_t<T, 3, 2, NTHR, SP>(a, stream);
     else if (a.k == 5 && a.s == 1) launch_t<T, 5, 1, NTHR, SP>(a, stream);
@@ -562,6 +580,7 @@ int front_threads(const FrontPlan& p, int n) {
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream) {
     WHENET_REQUIRE(!a.split || (dtype == WHENET_F32 && a.weps != nullptr && a.KSes == ceil_div(a.Cin, 16)), WHENET_EINVAL,
                    "front: the split-product form needs float32 storage and the split weight images");
+    WHENET_REQUIRE(a.in_gate == nullptr || a.split, WHENET_EINVAL, "front: the gated-input form needs the split-product form");
     if (dtype == WHENET_F16) launch_thr<half_t>(a, stream);
     else if (a.split) launch_thr<float, true>(a, stream);
     else launch_thr<float>(a, stream);

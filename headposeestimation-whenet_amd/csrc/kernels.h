@@ -215,6 +215,8 @@ struct FrontArgs {
     const void* weps = nullptr;    // [hi image | lo image] of the expand weights
     int KSes = 0;                  // ceil(Cin / 16)
     float wsi = 1.0f;
+    const float* in_gate = nullptr; // split only: [n][Cin] f32 -- the expand contracts (in_gate[crop] * x): block 2 fed by block 1's
+                                    // depthwise output with block 1's project folded into weps (engine.cpp, option fold12)
 };
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);
@@ -259,6 +261,35 @@ struct Front2Args {
 };
 void launch_front2(const Front2Args& a, hipStream_t stream);
 std::string kernel_name_front2(int k, int s, int kse, int threads, int xs, bool gated);
+
+// ---- front2s.hip ------------------------------------------------------------------------
+// WHENET_F32S (float32 storage): the same stage with both convolutions on the matrix cores -- expand as binary16 hi/lo
+// products (PwOps<float, true>), taps as per-channel Toeplitz products, tile in LDS at float32 precision.
+struct Front2sArgs {
+    const void* x;         // [n,H,H,Cin] float, or (pre) [n,H,H][hi Cin | lo Cin] binary16 pairs written by the producer
+    const void* weps;      // [hi image | lo image] of the expand weights (snapshot.cpp::pack_pw_split)
+    const float* be;       // [Cexp]
+    const void* wdt;       // pack_dw_toeplitz_s() image of the depthwise kernel for tap mode tm
+    const float* bd;       // [Cexp]
+    void* out;             // [n,Ho,Ho,Cexp] float
+    float* rpart;          // as FrontArgs::rpart
+    const float* w1t;      // [R][Cexp] se_reduce kernel, transposed, or NULL
+    int R;
+    int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
+    float wsi = 1.0f;      // 2^-shift of the scaled expand weights
+    float wsi_d = 1.0f;    // 2^-shift of the scaled depthwise taps (tm = 1)
+    int tm = 2;            // taps: 1 = binary16 hi/lo pairs on v_mfma_f32_4x4x4_16B_f16, 2 = exact float32 on v_mfma_f32_4x4x1_16B_f32
+    bool pre = false;      // x is in the pre-split pair form
+    Front2Plan plan;       // from make_front2s_plan() (16 bytes per 4-pixel group)
+};
+bool front2s_supported(int k, int s, int H, int Cin);
+bool front2s_preferred(int k, int s, int H, int Cexp);
+Front2Plan make_front2s_plan(int k, int s, int Ho, int Cexp, int CC, int TH, int TXG, int threads);
+Front2Plan plan_front2s(int k, int s, int H, int Ho, int Cexp, int* tm);
+std::vector<Front2Plan> plan_front2s_candidates(int k, int s, int Ho, int Cexp);
+std::vector<float> pack_dw_toeplitz_s(const std::vector<float>& w, int k, int s, int C, int tm, float* wsi);
+void launch_front2s(const Front2sArgs& a, hipStream_t stream);
+std::string kernel_name_front2s(int k, int s, int kse, int threads, int tm, bool pre);
 
 // ---- front7.hip -------------------------------------------------------------------------
 // the 7 x 7 blocks (13-16), both dtypes: the same stage with a GROUP of G crops per workgroup, the image-only LDS tile (no halo)

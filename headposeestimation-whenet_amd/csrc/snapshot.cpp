@@ -299,7 +299,7 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype,
                 c.shift[n] += p1.shift[j] * w;
                 for (uint32_t k = 0; k < K; ++k) c.wf[size_t(k) * N + n] += p1.wf[size_t(k) * J + j] * w;
             }
-        m.fold12 = pack_pw(c, K, N, dtype);
+        m.fold12 = pack_pw(c, K, N, dtype, split);
         // the f32 image front2.hip scales by the crop's gate before rounding: the f16 fragment order (16 k per step,
         // lane l <-> n = 32 ntile + (l & 31), k = 16 ks + 8 (l >> 5) + e), whatever the handle's dtype
         const int KS = ceil_div(int(K), 16), NT = ceil_div(int(N), 32);

@@ -94,6 +94,76 @@ def test_f32s_block_kernels_within_f32_tolerance(hs, blob, index):
     assert rel_err(r["out"], taps[f"b{index}/out"]) < 6e-5
 
 
+@pytest.mark.parametrize("index", list(range(2, 13)))
+def test_front2s_kernel_on_every_block_shape(hs, index):
+    """Round 6: front2s.hip -- expand as binary16 hi/lo products with pixels as MFMA rows, depthwise taps as per-channel Toeplitz
+    products on the matrix cores (exact float32 on v_mfma_f32_4x4x1 or hi/lo pairs on v_mfma_f32_4x4x4_f16, per layer), the
+    expanded tile at float32 precision in LDS.  Option front_impl=2 runs it on every block it exists for (2-12); held to the
+    per-kernel float32 tolerance against the oracle's depthwise output and to front.hip's own result."""
+    taps = {}
+    crops = np.load(os.path.join(GOLD, "golden_crops.npy"))[:3]
+    O.forward(crops, W.synthetic(1234), np.float64, taps=taps)
+    x = taps[f"b{index - 1}/out"].astype(np.float32)
+    outs = {}
+    for impl in (0, 2):
+        hs.set_option("front_impl", impl)
+        hs.set_option("se_fuse", 0)
+        try:
+            outs[impl] = hs.op_block(index, x)
+        finally:
+            hs.set_option("front_impl", 1)
+            hs.set_option("se_fuse", 1)
+    r = outs[2]
+    assert not np.array_equal(r["dw"], outs[0]["dw"]), "front_impl=2 did not change the kernel"
+    assert rel_err(r["dw"], taps[f"b{index}/dw"]) < 2e-5, "dw"
+    assert rel_err(r["dw"], outs[0]["dw"]) < 2e-5, "front2s vs front.hip"
+    assert rel_err(r["gate"], taps[f"b{index}/gate"].reshape(r["gate"].shape)) < 4e-5, "gate"
+    assert rel_err(r["out"], taps[f"b{index}/out"]) < 6e-5, "out"
+
+
+def test_front2s_everywhere_meets_the_bar_and_is_batch_invariant(hs):
+    fx = np.load(os.path.join(GOLD, "f16_set512_expected.npz"))
+    crops = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])[:128]
+    ydef, _, ldef = hs.forward(crops)
+    hs.set_option("front_impl", 2)
+    try:
+        y, a, l = hs.forward(crops)
+        for n in (1, 3, 17, 64):
+            yn, an, ln = hs.forward(crops[:n])
+            assert np.array_equal(ln, l[:n]), n
+    finally:
+        hs.set_option("front_impl", 1)
+    assert np.abs(y - fx["angles"][:128]).max() <= 1e-3
+    safe = fx["margins"][:128] > 2e-3
+    assert np.array_equal(a[safe], fx["argmax"][:128][safe])
+    assert not np.array_equal(l, ldef)
+    hs.set_option("front_impl", 0)               # round 5's schedule: front.hip on every block
+    try:
+        y0, a0, l0 = hs.forward(crops)
+    finally:
+        hs.set_option("front_impl", 1)
+    assert np.abs(y0 - fx["angles"][:128]).max() <= 1e-3 and not np.array_equal(l0, ldef)
+
+
+def test_f32s_fold12(hs):
+    """Round 6: block 1's project conv folded into block 2's expand weights for f32s too (front.hip's split form multiplies its
+    float32 operand by block 1's gate before the hi/lo split): one launch less, the same bar, another rounding path."""
+    fx = np.load(os.path.join(GOLD, "f16_set512_expected.npz"))
+    crops = np.concatenate([synth.scene_crops(256, seed=41), synth.noise_crops(256, seed=42)])[:96]
+    k1 = hs.info().n_kernels_per_forward
+    y1, a1, l1 = hs.forward(crops)
+    hs.set_option("fold12", 0)
+    try:
+        k0 = hs.info().n_kernels_per_forward
+        y0, a0, l0 = hs.forward(crops)
+    finally:
+        hs.set_option("fold12", 1)
+    assert k1 == k0 - 1
+    assert np.abs(y1 - fx["angles"][:96]).max() <= 1e-3 and np.abs(y0 - fx["angles"][:96]).max() <= 1e-3
+    assert not np.array_equal(l0, l1) and np.abs(l0 - l1).max() < 2e-4
+    assert np.array_equal(hs.forward(crops[7:8])[2][0], l1[7])
+
+
 def test_f32s_head_conv_and_pooling(hs):
     taps = {}
     crops = np.load(os.path.join(GOLD, "golden_crops.npy"))[:5]
