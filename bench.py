@@ -435,11 +435,17 @@ def summarise_profile(stats, crops_per_launch=None):
         k["flops"] += st["alg_flops"]
         k["launches"] += 1
         k["swish"] += sw.get(st["layer"], 0) * crops_per_launch
-    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["us"])
+    # the dominant kernel is the dominant LAUNCH (one layer of the chain), not the largest sum over a template name: round 5's
+    # line flipped between block 2's front kernel (one 64 us launch) and the 7 x 7 project GEMM (five 13 us launches)
+    top = max(stats, key=lambda st: st["avg_us"])
+    dom_name = top["kernel"]
+    dom = {"us": top["avg_us"], "bytes": top["alg_bytes"], "flops": top["alg_flops"], "launches": 1, "kind": top["kind"],
+           "swish": sw.get(top["layer"], 0) * crops_per_launch, "layer": top["layer"]}
     achieved = dom["bytes"] / (dom["us"] * 1e-6) / 1e9
     valu_floor_us = dom["swish"] / 64.0 * SWISH_CYCLES_PER_WAVE_VALUE / SIMDS / (SHADER_GHZ * 1e3)
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "kernel": dom_name, "launches_per_step": dom["launches"], "avg_launch_us": dom["us"] / dom["launches"],
+            "kernel": dom_name, "layer": dom["layer"], "launches_per_step": dom["launches"], "avg_launch_us": dom["us"] / dom["launches"],
+            "selection": "the launch of the chain with the largest average duration (by layer)",
             "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
             "tflops": dom["flops"] / (dom["us"] * 1e-6) / 1e12,
             "valu": {"what": "the kernel's Swish activations alone on the 1024 SIMDs: 5 VALU instructions per value, 2 of "
@@ -498,14 +504,23 @@ def sweep_leg(blob, local_rank, dev, lanes_opt):
             steps = int(min(2000, max(6, 0.1 / max(probe, 1e-5))))
             els = sorted(region(nslots, steps) for _ in range(3))
             entry[key] = {"crops_s": nb * steps / els[1], "ms_per_step": els[1] / steps * 1e3, "steps": steps}
-        stats = h.profile(d_crops.data_ptr(), nb, 3)
-        _, _, _, _, roof, _ = summarise_profile(stats)
+        stats = h.profile(d_crops.data_ptr(), nb, 3 if dt == _lib.F16 else 10)
+        cpl = stats[0]["crops"]
+        _, _, dname, dtop, roof, _ = summarise_profile(stats)
         res[key_of(nb, dt)] = {"value": entry["inflight3"]["crops_s"], "value_serial": entry["serial"]["crops_s"],
                          "ms_per_step": entry["inflight3"]["ms_per_step"], "ms_per_step_serial": entry["serial"]["ms_per_step"],
                          "steps": entry["inflight3"]["steps"], "dtype": {_lib.F16: "f16", _lib.F32: "f32", _lib.F32S: "f32s"}[dt],
                          "dominant_kernel": {"kernel": roof["kernel"], "avg_launch_us": roof["avg_launch_us"],
                                              "crops_per_launch": stats[0]["crops"],
                                              "frac_hbm": roof["frac"], "frac_valu": roof["valu"]["frac"]}}
+        if dt != _lib.F16:
+            # the parity-grade configurations carry a roofline object of their own (same method as the headline's)
+            dts = "f32" if dt == _lib.F32 else "f32s"
+            tr, tr_src, tr_extra = pmc_traffic(dts, nb, cpl, dname, dtop["layer"])
+            roof.update({"traffic": tr, "traffic_source": tr_src, "pmc": tr_extra, "crops_per_launch": cpl,
+                         "traffic_over_alg_bytes": (tr / roof["alg_bytes_per_launch"]) if tr else None,
+                         "chain_us_per_step": sum(st["avg_us"] for st in stats if st["kind"] != "calib")})
+            res[key_of(nb, dt)]["roofline"] = roof
         h.close()
     # f32s: parity of THIS run's f32s forward against the float64 oracle on the driver's 16 check crops (the 512-crop contract is
     # tests/test_f32s.py)
@@ -618,12 +633,12 @@ def numa_bind(comm: Comm, local_rank: int):
     return bind_rank_to_gpu_numa(bus, index_on_node=same.index(comm.rank), peers_on_node=len(same))
 
 
-def pmc_traffic(dtype: str, B: int, crops_per_launch: int, dom_name: str):
+def pmc_traffic(dtype: str, B: int, crops_per_launch: int, dom_name: str, dom_layer: str = ""):
     """HBM traffic of the dominant kernel from the committed PMC passes (tools/pmc_round.sh): only a set collected at
     the SAME crops per launch as the profile ran is comparable with `alg_bytes_per_launch`; otherwise traffic is null
     (round 3 printed a 32-crop figure next to 64-crop algorithmic bytes)."""
     tried = []
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", rnd, f"pmc_traffic_{dtype}_b{B}.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -638,7 +653,12 @@ def pmc_traffic(dtype: str, B: int, crops_per_launch: int, dom_name: str):
         if tk is None:
             tried.append(f"{rel}: holds crops_per_launch {sorted(sets)} -- not {crops_per_launch}, refused")
             continue
-        for name, v in tk["kernels"].items():
+        cands = []
+        lay = (tk.get("layers") or {}).get(dom_layer)
+        if lay is not None:                       # round 6: counters per LAYER (tools/pmc_summary.py with the chain's launch list)
+            cands.append((dom_name, lay))
+        cands += list(tk["kernels"].items())
+        for name, v in cands:
             if name.replace(" ", "") == dom_name.replace(" ", ""):
                 extra = {k2: v[k2] for k2 in ("valu_active_pct_of_wave_cycles", "valu_insts_per_wave", "mfma_busy_pct_of_cu_cycles",
                                               "waves_per_simd", "lds_bank_conflict_pct", "wait_pct_of_wave_cycles",
@@ -646,7 +666,8 @@ def pmc_traffic(dtype: str, B: int, crops_per_launch: int, dom_name: str):
                 src = (f"{rel} [crops_per_launch {crops_per_launch}]: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE in "
                        f"separate passes (tools/pmc_round.sh) of ONE chain of {crops_per_launch} crops run alone (the counters "
                        f"are device-wide: with chains side by side a kernel's figures include the others' traffic); the "
-                       f"same launch geometry whenet_profile() timed; committed file -- NOT re-measured by this run")
+                       f"same launch geometry whenet_profile() timed; committed file -- NOT re-measured by this run" +
+                       (f"; counters of layer {dom_layer} alone" if v is lay else "; averaged over every launch of this kernel name"))
                 return v["hbm_bytes_per_launch"], src, extra
         tried.append(f"{rel}: kernel {dom_name} not in the set")
     return None, ("no PMC set matches the profiled launch (" + "; ".join(tried) + ")") if tried else None, None
@@ -746,7 +767,7 @@ def main():
         st["raw_us"] = st["avg_us"]
     # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in separate
     # rocprofv3 --pmc passes of this same command and committed under profiles/): per launch, bytes
-    traffic, traffic_source, pmc_extra = pmc_traffic(args.dtype, B, crops_per_launch, dom_name)
+    traffic, traffic_source, pmc_extra = pmc_traffic(args.dtype, B, crops_per_launch, dom_name, dom["layer"])
     roofline.update({"traffic": traffic, "traffic_source": traffic_source, "pmc": pmc_extra,
                 "traffic_over_alg_bytes": (traffic / roofline["alg_bytes_per_launch"]) if traffic else None,
                 "crops_per_launch": crops_per_launch, "chains_profiled": chains,
@@ -879,6 +900,21 @@ def main():
         out["yolo_postprocess"] = yolo_leg(h)
     if rank == 0 and world == 1 and not distributed and not args.no_sweep and args.dtype == "f16" and B == 64 and not args.strong:
         out["sweep"] = sweep_leg(blob, local_rank, dev, args.lanes)
+    if "sweep" in out:
+        # the parity-grade figure as a first-class number: the faster of the two float32-storage configurations (both hold the
+        # north_star bar: <= 1e-3 deg, exact argmax -- tests/test_gpu_parity.py, tests/test_f32s.py) at the headline batch
+        pk = max(("f32_b64", "f32s_b64"), key=lambda k: out["sweep"][k]["value"])
+        pe = out["sweep"][pk]
+        out["parity_value"], out["parity_dtype"] = pe["value"], pe["dtype"]
+        out["parity_value_serial"] = pe["value_serial"]
+        out["parity_roofline"] = pe.get("roofline")
+        out["parity_note"] = (f"sweep.{pk}: batch 64, crops resident in HBM, 3 forwards in flight (parity_value_serial: one at a time); "
+                              "`value` above is the binary16 configuration BASELINE.json configs[2] names, which does NOT meet the 1e-3 deg bar")
+        out["config"]["workload"] += (f"; value = {M} forwards of the batch in flight ({value:.0f} crops/s), value_serial = one forward at a "
+                                      f"time ({out['value_serial']:.0f} crops/s); parity-grade ({pe['dtype']}): {pe['value']:.0f} crops/s")
+    elif out.get("value_serial") is not None:
+        out["config"]["workload"] += (f"; value = {M} forwards of the batch in flight ({value:.0f} crops/s), value_serial = one forward at a "
+                                      f"time ({out['value_serial']:.0f} crops/s)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     h.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSVs (one directory per pass, prefix + 1..N) per kernel NAME: averages
 over every dispatch of the run (the timed region and the profile pass launch the same sub-batch
-geometry).  usage: pmc_summary.py gpurun_out/pmc_f16_b64_c64_p [traffic.json crops_per_launch]
+geometry).  usage: pmc_summary.py gpurun_out/pmc_f16_b64_c64_p [traffic.json crops_per_launch [layers.json]]
 The traffic JSON holds one set per crops-per-launch ("by_crops_per_launch"): an existing file is updated, not replaced."""
 import csv
 import glob
@@ -46,12 +46,28 @@ def short(n):
     return _cache[n]
 
 
-agg = defaultdict(lambda: {"n": defaultdict(int), "c": defaultdict(float), "t": 0.0, "tn": 0})
+def new_agg():
+    return defaultdict(lambda: {"n": defaultdict(int), "c": defaultdict(float), "t": 0.0, "tn": 0, "kernel": ""})
+
+
+agg = new_agg()
+# round 6: the same counters per LAYER.  With the chain's launch list (bench.py --dump-layers of the SAME command: fifth argument)
+# every forward of a pass is the same sequence of launches, so a dispatch's position in its forward names its layer -- kernels that
+# several layers share (front.hip's float instantiation runs b2 and b6; the split-K GEMM five blocks) get a row per layer.
+layer_names, layer_kernels = [], []
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+    for l in json.load(open(sys.argv[4]))["launches"]:
+        if l.get("kind") != "calib":
+            layer_names.append(l["layer"])
+            layer_kernels.append(l["kernel"])
+lagg = new_agg()
+layer_note = None
 for d in sorted(glob.glob(prefix + "[0-9]")):
     f = glob.glob(d + "/*counter_collection.csv")
     if not f:
         continue
     seen = set()
+    rows_by_dispatch = defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         if "whenet" not in r["Kernel_Name"]:
             continue
@@ -64,6 +80,30 @@ for d in sorted(glob.glob(prefix + "[0-9]")):
             seen.add(key)
             a["t"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             a["tn"] += 1
+        if "whenet_empty_kernel" not in r["Kernel_Name"]:
+            rows_by_dispatch[int(r["Dispatch_Id"])].append(r)
+    if layer_names:
+        order = sorted(rows_by_dispatch)
+        L = len(layer_names)
+        base = lambda n: n.replace(" ", "").split("<")[0].split("EPK")[0]
+        if len(order) % L != 0:
+            layer_note = f"{d}: {len(order)} chain dispatches are not a multiple of the {L} launches of a forward -- no per-layer rows"
+            continue
+        for i, did in enumerate(order):
+            rs = rows_by_dispatch[did]
+            li = i % L
+            if base(short(rs[0]["Kernel_Name"])) != base(layer_kernels[li]):
+                layer_note = f"{d}: dispatch {did} is {short(rs[0]['Kernel_Name'])}, the launch list says {layer_kernels[li]} -- no per-layer rows"
+                lagg = new_agg()
+                layer_names = []
+                break
+            a = lagg[layer_names[li]]
+            a["kernel"] = short(rs[0]["Kernel_Name"])
+            for r in rs:
+                a["c"][r["Counter_Name"]] += float(r["Counter_Value"])
+                a["n"][r["Counter_Name"]] += 1
+            a["t"] += (int(rs[0]["End_Timestamp"]) - int(rs[0]["Start_Timestamp"])) / 1e3
+            a["tn"] += 1
 
 
 def avg(a, name):
@@ -71,6 +111,23 @@ def avg(a, name):
 
 
 print(f"{'kernel':52s}{'us':>7s} {'act%':>6s} {'valu%':>6s} {'lds%':>5s} {'wait%':>6s} {'ldsconf%':>8s} {'fetchMB':>8s} {'writeMB':>8s} {'L2hit%':>6s} {'valu/wv':>8s} {'vmemRD/wv':>9s}")
+def row_of(a):
+    wc = avg(a, "SQ_WAVE_CYCLES") or 1
+    waves = avg(a, "SQ_WAVES") or 1
+    hit, miss = avg(a, "TCC_HIT_sum"), avg(a, "TCC_MISS_sum")
+    fetch = 2 * avg(a, "FETCH_SIZE") * 1024
+    write = avg(a, "WRITE_SIZE") * 1024
+    busy_cu, mfma_busy = avg(a, "SQ_BUSY_CU_CYCLES"), avg(a, "SQ_VALU_MFMA_BUSY_CYCLES")
+    return {"kernel": a.get("kernel", ""), "dispatches_seen": a["tn"], "avg_us_under_pmc": a["t"] / max(a["tn"], 1),
+            "hbm_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+            "valu_active_pct_of_wave_cycles": 100 * avg(a, "SQ_ACTIVE_INST_VALU") / wc,
+            "valu_insts_per_wave": avg(a, "SQ_INSTS_VALU") / waves,
+            "wait_pct_of_wave_cycles": 100 * avg(a, "SQ_WAIT_ANY") / wc,
+            "l2_hit_pct": 100 * hit / ((hit + miss) or 1),
+            "mfma_busy_pct_of_cu_cycles": (100 * mfma_busy / (4 * busy_cu)) if busy_cu else None,
+            "lds_bank_conflict_pct": 100 * avg(a, "SQ_LDS_BANK_CONFLICT") / (avg(a, "SQ_ACTIVE_INST_LDS") or 1)}
+
+
 out = {}
 mfma_rows = []
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["t"]):
@@ -104,6 +161,25 @@ if any(r[2] for r in mfma_rows):
     print(f"{'kernel':52s}{'us':>7s} {'mfma_busy':>11s} {'mops_f16':>10s} {'insts_mfma':>10s} {'busy_cu':>11s} {'util/busyCU%':>12s}")
     for k, us, mb, mops, im, bc, gui in mfma_rows:
         print(f"{k:52s}{us:7.1f} {mb:11.0f} {mops:10.0f} {im:10.0f} {bc:11.0f} {100 * mb / (4 * bc) if bc else 0:12.2f}")
+layers_out = {}
+if lagg:
+    alg = {}
+    if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+        alg = {l["layer"]: l for l in json.load(open(sys.argv[4]))["launches"]}
+    print()
+    print(f"{'layer':14s}{'us':>7s} {'valu%':>6s} {'wait%':>6s} {'fetchMB':>8s} {'writeMB':>8s} {'algMB':>7s} {'x alg':>6s} {'L2hit%':>6s} {'mfma%':>6s} {'valu/wv':>8s}  kernel")
+    for name in layer_names:
+        r = row_of(lagg[name])
+        ab = alg.get(name, {}).get("alg_bytes", 0.0)
+        r["alg_bytes_per_launch"] = ab
+        r["traffic_over_alg_bytes"] = (r["hbm_bytes_per_launch"] / ab) if ab else None
+        layers_out[name] = r
+        print(f"{name:14s}{r['avg_us_under_pmc']:7.1f} {r['valu_active_pct_of_wave_cycles']:6.1f} {r['wait_pct_of_wave_cycles']:6.1f} "
+              f"{r['fetch_bytes_per_launch'] / 1e6:8.2f} {r['write_bytes_per_launch'] / 1e6:8.2f} {ab / 1e6:7.2f} "
+              f"{(r['traffic_over_alg_bytes'] or 0):6.2f} {r['l2_hit_pct']:6.1f} {(r['mfma_busy_pct_of_cu_cycles'] or 0):6.2f} "
+              f"{r['valu_insts_per_wave']:8.0f}  {r['kernel'][:70]}")
+if layer_note:
+    print("\nper-layer rows: " + layer_note)
 if len(sys.argv) > 2:
     cpl = str(int(sys.argv[3])) if len(sys.argv) > 3 else None
     if cpl is None:
@@ -121,4 +197,6 @@ if len(sys.argv) > 2:
                     "here with the known read volumes of the expand and depthwise kernels); averages per dispatch; one "
                     "set per crops-per-launch of the profiled chain (ONE chain alone on the GPU: tools/pmc_round.sh)")
     blob["by_crops_per_launch"][cpl] = {"crops_per_launch": int(cpl), "source": prefix, "kernels": out}
+    if layers_out:
+        blob["by_crops_per_launch"][cpl]["layers"] = layers_out
     json.dump(blob, open(sys.argv[2], "w"), indent=1)
