@@ -78,6 +78,14 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype)
         b.se.w2 = upload(hb.se.w2);
         b.se.w2c = upload(hb.se.w2c);
         b.se.b2 = upload(hb.se.b2);
+        if (split_ && !hb.se.excite.packed_split.empty()) {
+            b.se.w2p = upload_bytes(hb.se.excite.packed_split.data(), hb.se.excite.packed_split.size());
+            b.se.KSr = hb.se.excite.KS_split;
+            b.se.w2_wsi = hb.se.excite.wsi;
+        } else if (dtype_ == WHENET_F16 && !hb.se.excite.packed.empty()) {
+            b.se.w2p = upload_bytes(hb.se.excite.packed.data(), hb.se.excite.packed.size());
+            b.se.KSr = hb.se.excite.KS;
+        }
         b.project = upload_pw(hb.project);
         partial_per_crop_ = std::max(partial_per_crop_, size_t(b.dw.plan.ntiles()) * b.dw.C);
         if (hb.spec.has_expand()) {
@@ -207,7 +215,8 @@ void Engine::set_option(const std::string& key, long value) {
         sync();
         drop_graphs();
     } else if (key == "se_fuse") {
-        WHENET_REQUIRE(value >= 0 && value <= 2, WHENET_EINVAL, "se_fuse must be 0 (never), 1 (where it pays) or 2 (always)");
+        WHENET_REQUIRE(value >= 0 && value <= 3, WHENET_EINVAL,
+                       "se_fuse must be 0 (never), 1 (where the prologue form pays), 2 (prologue form on every block) or 3 (1 + the matrix-core form on blocks 7-16, default)");
         se_fuse_ = int(value);
         sync();
         drop_graphs();
@@ -438,7 +447,14 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
     // saved pays -- EXCEPT on the 7 x 7 blocks (K = 1152), whose project workgroups would each pull the whole 221 KB excite
     // kernel: se_fuse=2 on all blocks measured 451 us against 420 us at B=1 (round 5).  Blocks 2-12 fuse; same bits either way.
     const bool tiny = !single_stage_call_ && n > 0 && n <= se_fuse_tiny_ && b.project.K < 1152;
-    r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || (se_fuse_ == 1 && (se_pays || tiny)));
+    // option se_fuse = 3 (round 6): as 1, plus the deep contractions (blocks 7 - 16): their LDS-staged split-K project GEMM computes the
+    // gate of each wave's own k-groups on the matrix cores (pw.hip GM = 3) -- f16 and f32s handles.  Ten launches fewer and SLOWER:
+    // every project workgroup pulls the 110 KB excite image through a CU that already fetches at its ~55 GB/s limit (f16, 64 crops:
+    // project 12.0 -> 17 us on 14x14, 13.1 -> 21.8 us on 7x7, against a 6.6 - 7.4 us squeeze-excite launch; B = 1: 288 -> 298 us;
+    // line 162 -> 157 k crops/s; profiles/r06/se_mfma_ab.txt).  Not the default.
+    r.se_mfma = r.se_in_front && pw_impl_ == 0 && se_fuse_ == 3 && pw_staged_ && b.project.K >= 320 && b.se.w2p != nullptr &&
+                (dtype_ == WHENET_F16 || (split_ && split_pw_));
+    r.se_fused = r.se_in_front && pw_impl_ == 0 && (se_fuse_ == 2 || r.se_mfma || ((se_fuse_ == 1 || se_fuse_ == 3) && (se_pays || tiny)));
     return r;
 }
 
@@ -667,6 +683,11 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         sef.R = b.se.R;
         sef.RP = se_padded_r(b.se.R);
         sef.inv_hw = 1.0f / float(hw_out);
+        if (bs.se_mfma) {
+            sef.w2p = b.se.w2p;
+            sef.KSr = b.se.KSr;
+            sef.w2_wsi = b.se.w2_wsi;
+        }
     } else if (se_in_front) {
         // the front kernel already applied se_reduce to its channel sums (v.partial holds the
         // (tiles x chunks) partial vectors of every crop): finish the SEBlock

@@ -38,6 +38,9 @@ struct DevSe {
     int C = 0, R = 0;
     float *w1t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
     float* w2c = nullptr;      // [C][RP] (se.hip reads a channel's whole excite row with 16-byte loads)
+    void* w2p = nullptr;       // the excite kernel as an MFMA operand image (HostSe::excite), or nullptr
+    int KSr = 0;
+    float w2_wsi = 1.0f;
 };
 struct DevBlock {
     BlockSpec spec;
@@ -173,7 +176,7 @@ class Engine {
     bool stem_fuse_active() const;
     bool fold12_active() const;
     struct BlockSchedule {     // which kernels a block runs under the current options
-        bool fused = false, use_f2 = false, use_f2s = false, use_f7 = false, se_in_front = false, se_fused = false;
+        bool fused = false, use_f2 = false, use_f2s = false, use_f7 = false, se_in_front = false, se_fused = false, se_mfma = false;
         int se_ntiles = 1, se_chunks = 1;
     };
     // n = crops of the chain the block runs in (0: not batch-specific, e.g. the launch count of get_info)

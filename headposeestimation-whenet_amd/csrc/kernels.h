@@ -91,6 +91,11 @@ struct SeFuse {            // second half of a SEBlock computed by the project G
     const float* b2 = nullptr;       // [C]
     int np = 0, R = 0, RP = 0;
     float inv_hw = 0.f;
+    // round 6 (GM = 3, the LDS-staged split-K kernel): every wave computes the gate of the k-groups IT owns on the matrix cores from
+    // this operand image of the excite kernel ([ceil(R/16)][K/32][64 lanes][8] binary16; f32s: [hi | lo] images scaled by 2^shift)
+    const void* w2p = nullptr;
+    int KSr = 0;                     // ceil(R / 16)
+    float w2_wsi = 1.0f;             // f32s: 2^-shift
 };
 struct PwArgs {
     const void* a;         // [M][K] T

@@ -305,6 +305,15 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_staged_
     constexpr int GCROPS = MB + 1, GK = 1152;
     __shared__ __attribute__((aligned(16))) T s_gate[GATE ? GCROPS * GK : 8];
     __shared__ float s_r[GM == 2 ? GCROPS * 48 : 4];
+    // GM == 3 (round 6): the gate on the matrix cores, per wave, for the k-groups the wave owns -- no workgroup-wide stage, no barrier.
+    //   z[crop][c] = sum_j r[crop][j] * W2[j][c]  is a v_mfma_f32_32x32x16_f16 product with the crops' r vectors as rows 0 / 4 / 8 / 12
+    //   (the accumulator then holds crop 2 s + (lane >> 5) of channel (lane & 31) in register 4 s) and a 32-channel tile of the excite
+    //   kernel's operand image as columns: ceil(R / 16) instructions per tile (f32s: three, hi/lo pairs), two tiles per 128-byte group
+    //   (f32s: one).  r itself is computed by every wave (lanes = j; the np partial vectors of its <= 3 crops) with se.hip's arithmetic.
+    constexpr int GT = 128 / int(sizeof(T)) / 32;         // excite tiles per k-group: 2 (binary16 rows) | 1 (float rows)
+    constexpr int KSRM = 3;                               // ceil(R / 16) <= 3 (R <= 48)
+    constexpr int NIMG = SP ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) half_t s_rw[GM == 3 ? 4 * NIMG * 4 * 48 : 8];      // [wave][hi | lo][crop 0..3][48]
 
     const int id = blockIdx.x;
     const int q = id >> 3;
@@ -416,10 +425,93 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_staged_
         }
     };
 
+    // ---- GM == 3: excite operands of a k-group, and the group's gate ---------------------------------------------------------
+    struct GW {
+        half8 w[NIMG][KSRM][GT];
+        float b2[GT];
+    };
+    const int NTse = K >> 5;                                // 32-channel tiles of the excite kernel (K is a multiple of 32 here)
+    const half8* w2img = reinterpret_cast<const half8*>(se.w2p);
+    const size_t w2_lo = size_t(se.KSr) * NTse * 64;        // (f32s) fragments between the hi and the lo image
+    auto issue_g = [&](int gi, GW& gw) {
+        if constexpr (GM == 3) {
+            const int gic = gi < NG ? gi : NG - 1;
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const int tile = gic * GT + t, tilec = tile < NTse ? tile : NTse - 1;
+#pragma unroll
+                for (int ks = 0; ks < KSRM; ++ks) {
+                    const size_t idx = (size_t(ks < se.KSr ? ks : se.KSr - 1) * NTse + tilec) * 64 + lane;
+                    gw.w[0][ks][t] = w2img[idx];
+                    if constexpr (SP) gw.w[1][ks][t] = w2img[w2_lo + idx];
+                }
+                gw.b2[t] = se.b2[tilec * 32 + j];
+            }
+        }
+    };
+    // the crops' r vectors as the products' row operand: rows 0 / 4 / 8 / 12 carry crops 0..3 (read from the wave's LDS copy where
+    // they are multiplied: kept in registers they cost 12 - 24 VGPRs of a kernel that has none to spare at B2 = 2)
+    const half_t* rw_lane = s_rw + kpart * (NIMG * 4 * 48) + (((j >> 2) & 1) + 2 * (j >> 3)) * 48 + g * 8;
+    const bool rw_has = (j & 3) == 0 && j < 16;
+    auto rfrag = [&](int im, int ks) -> half8 {
+        return rw_has ? *reinterpret_cast<const half8*>(rw_lane + im * (4 * 48) + ks * 16) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    auto gate_group = [&](int gi, const GW& gw) {
+        if constexpr (GM == 3) {
+            if (gi >= NG) return;                           // (wave-uniform)
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const int tile = gi * GT + t;
+                if (tile >= NTse) continue;                 // (wave-uniform: K = 480 ends in half a group)
+                float16v z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KSRM; ++ks) {
+                    if (ks >= se.KSr) continue;             // (wave-uniform)
+                    const half8 rhi = rfrag(0, ks);
+                    if constexpr (SP) {
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(rhi, gw.w[1][ks][t], z, 0, 0, 0);            // (small terms first)
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(rfrag(1, ks), gw.w[0][ks][t], z, 0, 0, 0);
+                    }
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(rhi, gw.w[0][ks][t], z, 0, 0, 0);
+                }
+                const int ch = tile * 32 + j;
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int c = 2 * sl + g;               // the crop this lane holds in register 4 sl
+                    if (c < ncrop) {
+                        const float zz = SP ? fmaf(z[4 * sl], se.w2_wsi, gw.b2[t]) : z[4 * sl] + gw.b2[t];
+                        s_gate[c * K + ch] = T(sigmoid_f<SP>(zz));
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+    };
+    if constexpr (GM == 3) {
+        half_t* rw = s_rw + kpart * (NIMG * 4 * 48);
+        if (lane < 48) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float r = 0.f;
+                if (c < ncrop && lane < se.RP)
+                    r = se_fused_r(se.rpart + (size_t(crop_lo + c) * se.np) * se.RP + lane, se.np, se.RP, se.inv_hw,
+                                   lane < se.R ? se.b1[lane] : 0.f, lane < se.R);
+                const half_t hi = half_t(r);
+                rw[c * 48 + lane] = hi;
+                if constexpr (SP) rw[4 * 48 + c * 48 + lane] = half_t(r - float(hi));
+            }
+        }
+        wave_lds_sync();
+    }
+
     VT an[NLD];
     WF w0[KGS][NT], w1[KGS][NT];
+    GW g0, g1;
     issue_a(kpart, an);
     issue_w(kpart, w0);
+    issue_g(kpart, g0);
     if constexpr (GM == 1) {
         VT* dst = reinterpret_cast<VT*>(s_gate);
 #pragma unroll
@@ -430,16 +522,21 @@ __global__ __launch_bounds__(256, B2 == 2 ? 2 : 3) void whenet_pw_splitk_staged_
         lds_barrier();
     }
     if constexpr (GM == 2) se_fused_to_lds<T, 256>(se, crop_lo, ncrop, K, s_gate, s_r);
+    gate_group(kpart, g0);
     stage(an);
     for (int gi = kpart; gi < NG; gi += 8) {                // two groups per trip: the weight registers swap roles
         issue_a(gi + 4, an);
         issue_w(gi + 4, w1);
+        issue_g(gi + 4, g1);
         compute(gi, w0);
+        gate_group(gi + 4, g1);
         stage(an);
         if (gi + 4 < NG) {                                  // (wave-uniform)
             issue_a(gi + 8, an);
             issue_w(gi + 8, w0);
+            issue_g(gi + 8, g0);
             compute(gi + 4, w1);
+            gate_group(gi + 8, g0);
             stage(an);
         }
     }
@@ -773,12 +870,14 @@ PwChoice choose_pw(const PwArgs& a, int num_cus) {
 template <typename T, int B2, int GM, bool RES, int ACT, bool SP>
 void launch_splitk(const PwArgs& a, hipStream_t stream) {
     const int MT = ceil_div(a.M, 32 * B2), NCH = ceil_div(a.NTILES, B2);
-    if (use_staged(a, IsF32<T>::value && !SP))
+    if (GM == 3 || use_staged(a, IsF32<T>::value && !SP)) {
         hipLaunchKernelGGL((whenet_pw_splitk_staged_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
                            stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
                            static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
                            a.N, SP ? a.KSs : a.KS, a.NTILES, a.HW, MT, NCH, a.se, a.wsi);
-    else
+        return;
+    }
+    if constexpr (GM != 3)                  // (the matrix-core gate exists in the staged kernel only)
         hipLaunchKernelGGL((whenet_pw_splitk_kernel<T, B2, GM, RES, ACT, SP>), dim3(8 * ceil_div(MT, 8) * NCH), dim3(256), 0,
                            stream, static_cast<const T*>(a.a), static_cast<const T*>(SP ? a.wps : a.wp), a.bias,
                            static_cast<const T*>(a.gate), static_cast<const T*>(a.res), static_cast<T*>(a.out), a.M, a.K,
@@ -825,13 +924,27 @@ void launch_variant(const PwArgs& a, int impl, int num_cus, hipStream_t stream) 
 template <typename T, bool SP = false>
 void launch_dtype(const PwArgs& a, int impl, int num_cus, hipStream_t stream) {
     const bool res = a.res != nullptr;
-    const int gm = a.se.rpart != nullptr ? 2 : (a.gate != nullptr ? 1 : 0);
+    const int gm = a.se.rpart != nullptr ? (a.se.w2p != nullptr ? 3 : 2) : (a.gate != nullptr ? 1 : 0);
     // the network uses exactly these flavours: expand/head (swish), project (gate from memory | fused SE), + skip
     if (gm == 0 && !res && a.act == ACT_SWISH) launch_variant<T, 0, false, ACT_SWISH, SP>(a, impl, num_cus, stream);
     else if (gm == 1 && !res && a.act == ACT_NONE) launch_variant<T, 1, false, ACT_NONE, SP>(a, impl, num_cus, stream);
     else if (gm == 1 && res && a.act == ACT_NONE) launch_variant<T, 1, true, ACT_NONE, SP>(a, impl, num_cus, stream);
     else if (gm == 2 && !res && a.act == ACT_NONE) launch_variant<T, 2, false, ACT_NONE, SP>(a, impl, num_cus, stream);
     else if (gm == 2 && res && a.act == ACT_NONE) launch_variant<T, 2, true, ACT_NONE, SP>(a, impl, num_cus, stream);
+    else if (gm == 3 && a.act == ACT_NONE) {
+        // (the matrix-core gate lives in the LDS-staged split-K kernel only: deep contractions of binary16 / split-product handles)
+        WHENET_REQUIRE(impl == 0 && a.K >= 320 && a.K % 32 == 0 && (sizeof(T) == 2 || SP) && a.se.KSr >= 1 && a.se.KSr <= 3 &&
+                           a.se.RP <= 48, WHENET_EINVAL, "pointwise: the matrix-core squeeze-excite form is outside its limits");
+        if constexpr (sizeof(T) == 2 || SP) {
+            if (res) {
+                if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, 3, true, ACT_NONE, SP>(a, stream);
+                else launch_splitk<T, 1, 3, true, ACT_NONE, SP>(a, stream);
+            } else {
+                if (use_split2(a.M, a.NTILES)) launch_splitk<T, 2, 3, false, ACT_NONE, SP>(a, stream);
+                else launch_splitk<T, 1, 3, false, ACT_NONE, SP>(a, stream);
+            }
+        }
+    }
     else throw Error(WHENET_EINVAL, "pointwise: unsupported epilogue combination");
 }
 
@@ -860,7 +973,7 @@ void launch_pw(const PwArgs& a, int dtype, int impl, int num_cus, hipStream_t st
 std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
     // the instantiation launch_pw() will pick, spelled as rocprofv3 prints it
     const char* t = dtype == WHENET_F16 ? "_Float16" : "float";
-    const char* gate = a.se.rpart ? "2" : (a.gate ? "1" : "0");
+    const char* gate = a.se.rpart ? (a.se.w2p ? "3" : "2") : (a.gate ? "1" : "0");
     const char* res = a.res ? "true" : "false";
     char buf[96];
     if (impl == 1) {
@@ -869,7 +982,7 @@ std::string kernel_name_pw(const PwArgs& a, int dtype, int impl, int num_cus) {
         const PwChoice ch = choose_pw(a, num_cus);
         if (ch.kind == 1) {
             const int b2 = use_split2(a.M, a.NTILES) ? 2 : 1;
-            const bool st = use_staged(a, dtype == WHENET_F32 && !a.split);
+            const bool st = (a.se.rpart && a.se.w2p) || use_staged(a, dtype == WHENET_F32 && !a.split);
             std::snprintf(buf, sizeof(buf), "whenet_pw_splitk%s_kernel<%s, %d, %s, %s, %d%s>", st ? "_staged" : "", t, b2, gate, res, a.act,
                           a.split ? ", true" : (st ? ", false" : ""));
         }

@@ -272,6 +272,16 @@ HostModel build_host_model(const std::map<std::string, RawTensor>& t, int dtype,
             for (uint32_t j = 0; j < r; ++j)
                 for (uint32_t c = 0; c < cexp; ++c) hb.se.w2c[size_t(c) * rp + j] = w2[size_t(j) * cexp + c];
             hb.se.b2.assign(b2, b2 + cexp);
+            // round 6: the excite kernel as an MFMA operand image [ceil(R/16)][C/32][64 lanes][8] -- the project GEMMs of the 14x14 /
+            // 7x7 blocks compute gate = sigmoid(r . W2 + b2) for their own k-groups on the matrix cores (pw.hip, GM = 3): binary16 for
+            // f16 handles, [hi | lo] pairs for f32s; the exact-f32 configuration keeps the stand-alone kernel
+            if (dtype == WHENET_F16 || split) {
+                FoldedPw e;
+                e.wf.resize(size_t(r) * cexp);
+                for (size_t i = 0; i < e.wf.size(); ++i) e.wf[i] = double(w2[i]);
+                e.shift.assign(cexp, 0.0);
+                hb.se.excite = pack_pw(e, r, cexp, dtype, split);
+            }
         }
         hb.project = make_pw(t, p + "/project", p + "/project_bn", cexp, cout, dtype, split);
         m.blocks.push_back(std::move(hb));

@@ -53,6 +53,7 @@ struct HostSe {
     std::vector<float> w2;           // [R][C]  (se_expand kernel)
     std::vector<float> w2c;          // [C][RP] the same kernel channel-major, R zero-padded to a multiple of 4
     std::vector<float> b2;           // [C]
+    HostPw excite;                   // se_expand as an MFMA operand image, K = R, N = C (f16 handles: packed; f32s: packed_split); empty otherwise
 };
 
 struct HostBlock {

@@ -110,14 +110,16 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
 /* options: "graph" (0/1, default 1: replay the forward as a hipGraph),
  *          "fuse_front" (0/1, default 1: expand 1x1 + depthwise as ONE kernel per block, the
  *                  expanded tensor stays in LDS; 0 = two launches through HBM),
- *          "se_fuse" (0..2, default 1: second half of the squeeze-excite block inside the project conv's launch -- its
+ *          "se_fuse" (0..3, default 1: second half of the squeeze-excite block inside the project conv's launch -- its
  *                  workgroups compute the gate of their own rows' crops -- 0 = never (a squeeze-excite launch per block,
  *                  51 launches per forward, 50 with fold12), 2 = on every block with a fused front kernel (36 / 35 launches), 1 = on the
- *                  blocks where that is the faster schedule; the results are bitwise the same),
- *          "front_impl" (0..2, default 1: which fused kernel an f16 handle uses -- 0 = front.hip (depthwise taps
- *                  as f32 VALU FMAs) on every block, 2 = front2.hip (taps as Toeplitz products on the matrix
- *                  cores, f16 tap weights) on every block, 1 = per layer, whichever was measured faster;
- *                  f32 handles always run front.hip),
+ *                  blocks where that is the faster schedule; the results are bitwise the same;
+ *                  3 (round 6, f16 / f32s handles) = 1 plus blocks 7-16, whose project conv then computes the gate of each wave's own
+ *                  channel groups on the matrix cores: ten launches fewer, another rounding path, measured slower),
+ *          "front_impl" (0..2, default 1: which fused kernel a handle uses -- 0 = front.hip (depthwise taps
+ *                  as f32 VALU FMAs) on every block, 2 = the kernel with the taps as Toeplitz products on the matrix
+ *                  cores wherever it exists (f16: front2.hip, f16 tap weights; f32s: front2s.hip, exact-f32 or hi/lo taps;
+ *                  blocks 2-12), 1 = per layer, whichever was measured faster; exact-f32 handles always run front.hip),
  *          "front7" (0/1, default 1: with front_impl = 1, blocks 13-16 (7 x 7 maps) of an f16 handle run front7.hip -- a GROUP of
  *                  2 or 4 crops per workgroup, the image-only LDS tile, the chunk's expand weights staged once in LDS; the group
  *                  size follows the launch size and changes no bit of a crop's result; 0 = round 3's per-layer choice),

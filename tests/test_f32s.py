@@ -12,6 +12,7 @@ from tests import refcases as C
 from whenet_hip import _lib, spec, synth, weights as W
 
 pytestmark = pytest.mark.gpu
+SE_FUSE_DEFAULT = 1      # option se_fuse: the project GEMM computes the gate where that pays (blocks 4-6)
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -82,7 +83,7 @@ def test_f32s_block_kernels_within_f32_tolerance(hs, blob, index):
         try:
             r = hs.op_block(index, x)
         finally:
-            hs.set_option("se_fuse", 1)
+            hs.set_option("se_fuse", SE_FUSE_DEFAULT)
         assert rel_err(r["out"], taps[f"b{index}/out"]) < 6e-5, (index, se_fuse)
     hs.set_option("fuse_front", 0)           # the expand conv as a pointwise launch of its own (tile kernel, K = 16..192)
     try:
@@ -112,7 +113,7 @@ def test_front2s_kernel_on_every_block_shape(hs, index):
             outs[impl] = hs.op_block(index, x)
         finally:
             hs.set_option("front_impl", 1)
-            hs.set_option("se_fuse", 1)
+            hs.set_option("se_fuse", SE_FUSE_DEFAULT)
     r = outs[2]
     assert not np.array_equal(r["dw"], outs[0]["dw"]), "front_impl=2 did not change the kernel"
     assert rel_err(r["dw"], taps[f"b{index}/dw"]) < 2e-5, "dw"
