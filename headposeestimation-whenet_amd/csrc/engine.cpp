@@ -122,6 +122,15 @@ Engine::Engine(const void* snapshot, size_t nbytes, int device_id, int dtype)
                 partial_per_crop_ = std::max(partial_per_crop_, size_t(b.f7_chunks) * size_t(se_padded_r(b.se.R)));
             }
         }
+        if (mb7_supported(dtype_, hb.spec.k, hb.spec.s, hb.spec.h_in, hb.spec.cin, hb.dw.C, hb.se.R, hb.spec.cout, hb.spec.has_skip())) {
+            // f16, blocks 13-16: the whole block as one launch (mb7.hip, round 6) -- tap sequences and binary16 squeeze-excite kernels
+            std::vector<half_t> w1p, w2p;
+            pack_mb7_se(hb.se.w1t, hb.se.w2, hb.se.C, hb.se.R, &w1p, &w2p);
+            b.mb7.wds = upload(pack_mb7_taps(hb.dw.w, hb.spec.k, hb.dw.C));
+            b.mb7.w1p = upload(w1p);
+            b.mb7.w2p = upload(w2p);
+            b.mb7.ok = true;
+        }
         blocks_.push_back(b);
     }
     head_ = upload_pw(m.head);
@@ -236,6 +245,10 @@ void Engine::set_option(const std::string& key, long value) {
         head_fuse_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "mb7") {
+        mb7_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "front7") {
         front7_ = value != 0;
         sync();
@@ -316,6 +329,7 @@ void Engine::get_info(whenet_info_t* out) const {
         int k = 1 + 2;
         for (const DevBlock& b : blocks_) {
             const BlockSchedule bs = block_schedule(b);
+            if (bs.use_mb7) { k += 1; continue; }       // the whole block is one launch (mb7.hip)
             k += bs.fused ? 1 : (b.spec.has_expand() ? 2 : 1);
             k += bs.se_fused ? 1 : 2;                   // project alone when it computes the gate itself
         }
@@ -435,6 +449,8 @@ Engine::BlockSchedule Engine::block_schedule(const DevBlock& b, int n) const {
     BlockSchedule r;
     r.fused = fuse_front_ && b.spec.has_expand() && pw_impl_ == 0;
     r.use_f7 = r.fused && front_impl_ == 1 && front7_ && b.f7_supported;
+    // round 6: blocks 13-16 of an f16 handle as ONE launch (mb7.hip): one workgroup per crop, every intermediate tensor in LDS
+    r.use_mb7 = r.use_f7 && mb7_ && dtype_ == WHENET_F16 && b.mb7.ok;
     r.use_f2 = r.fused && !r.use_f7 && dtype_ == WHENET_F16 && (front_impl_ == 2 || (front_impl_ == 1 && b.f2_preferred));
     const bool f2s_pick = f2s_mask_ >= 0 ? ((f2s_mask_ >> b.spec.index) & 1) != 0 : b.f2s_preferred;     // (option "f2s_mask": probes)
     r.use_f2s = r.fused && !r.use_f7 && split_ && split_pw_ && b.f2s_supported && b.expand.wps != nullptr &&
@@ -503,6 +519,35 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
     WHENET_REQUIRE(fold == 0 || (fold == 1 && !fused && sp.index == 1) ||
                        (fold == 2 && sp.index == 2 && (use_f2 || (split_ && fused && !bs.use_f2s && !bs.use_f7))), WHENET_EINVAL,
                    "fold12: block outside the folded pair");
+    if (bs.use_mb7) {
+        WHENET_REQUIRE(fold == 0, WHENET_EINVAL, "mb7: block outside the 7 x 7 stage");
+        Mb7Args a{};
+        a.x = in;
+        a.wep = b.expand.wp;
+        a.be = b.expand.bias;
+        a.wds = b.mb7.wds;
+        a.bd = b.dw.bias;
+        a.w1p = b.mb7.w1p;
+        a.b1 = b.se.b1;
+        a.w2p = b.mb7.w2p;
+        a.b2 = b.se.b2;
+        a.wpp = b.project.wp;
+        a.bp = b.project.bias;
+        a.out = out;
+        if (single_stage_call_) {            // whenet_op_block reads the block's intermediate tensors back
+            a.dbg_dw = v.d;
+            a.dbg_gate = v.gate;
+        }
+        a.k = sp.k;
+        a.Cout = sp.cout;
+        a.skip = sp.has_skip();
+        a.n = n;
+        R(p + "/mbconv", "mbconv", kernel_name_mb7(sp.k, sp.cout, a.skip).c_str(),
+          double(n) * (hw_in * sp.cin * (a.skip ? 2 : 1) + hw_out * sp.cout) * es,
+          2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp + double(hw_out) * cexp * sp.cout),
+          [&] { launch_mb7(a, s); });
+        return;
+    }
     if (bs.use_f7) {
         Front7Args a{};
         a.dtype = dtype_;

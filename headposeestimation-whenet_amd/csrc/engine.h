@@ -42,6 +42,10 @@ struct DevSe {
     int KSr = 0;
     float w2_wsi = 1.0f;
 };
+struct DevMb7 {                 // f16, blocks 13-16: operand images of the one-launch block kernel (mb7.hip)
+    bool ok = false;
+    half_t *wds = nullptr, *w1p = nullptr, *w2p = nullptr;
+};
 struct DevBlock {
     BlockSpec spec;
     DevPw expand;
@@ -56,6 +60,7 @@ struct DevBlock {
     int f7_chunks = 1;         // channel chunks of its plans (the same for every group size: see front7_plan_for)
     DevSe se;
     DevPw project;
+    DevMb7 mb7;
 };
 
 // Collects one entry per kernel launch when profiling (event pair around each launch).
@@ -177,6 +182,7 @@ class Engine {
     bool fold12_active() const;
     struct BlockSchedule {     // which kernels a block runs under the current options
         bool fused = false, use_f2 = false, use_f2s = false, use_f7 = false, se_in_front = false, se_fused = false, se_mfma = false;
+        bool use_mb7 = false;  // the whole block is one launch (mb7.hip): no front / squeeze-excite / project launches
         int se_ntiles = 1, se_chunks = 1;
     };
     // n = crops of the chain the block runs in (0: not batch-specific, e.g. the launch count of get_info)
@@ -214,6 +220,10 @@ class Engine {
     bool head_fuse_ = true;     // option "head_fuse": the head conv pools its own output (head7.hip, f16 and f32); 0 = round 3's two stages
     bool front7_ = true;        // option "front7": blocks 13-16 of an f16 handle run front7.hip (a group of crops per workgroup)
                                 // when front_impl = 1; 0 = the per-layer choice of round 3 (front.hip there)
+    bool mb7_ = false;          // option "mb7": blocks 13-16 of an f16 handle run as ONE launch each (mb7.hip, round 6: one workgroup per crop,
+                                // every intermediate tensor in LDS).  Measured (profiles/r06/mb7_*): 29 us per launch whatever the batch up to 256
+                                // crops against 3 x 8 us at one crop and 67 us at 256 -- +3 % at batch 512, +-1 % at 64 x 3 in flight, -4 % one
+                                // forward at a time, +60 us at batch 1.  Not the default: the schedule must not depend on the batch.
     bool stem_fuse_ = true;     // option "stem_fuse": uint8 input -- the stem conv is computed inside block 1's depthwise kernel (stemdw.hip)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster

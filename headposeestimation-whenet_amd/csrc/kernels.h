@@ -331,6 +331,34 @@ struct Front7Args {
 void launch_front7(const Front7Args& a, hipStream_t stream);
 std::string kernel_name_front7(int dtype, int k, const Front7Plan& p, bool split = false);
 
+// ---- mb7.hip ----------------------------------------------------------------------------
+// f16, blocks 13-16 (7 x 7 maps, 192 -> 1152 -> 192 | 320): the whole MBConv block -- expand, depthwise, squeeze-excite, gate, project,
+// skip -- as ONE launch, one workgroup per crop, every intermediate tensor in LDS (round 6).
+struct Mb7Args {
+    const void* x;         // [n,7,7,192] half  block input (also the skip operand)
+    const void* wep;       // packed expand weights (MFMA fragment order, snapshot.h)
+    const float* be;       // [1152]
+    const void* wds;       // pack_mb7_taps() image of the depthwise kernel
+    const float* bd;       // [1152]
+    const void* w1p;       // pack_mb7_se(): se_reduce kernel, binary16 [1152][6][8]
+    const float* b1;       // [48]
+    const void* w2p;       // pack_mb7_se(): se_expand kernel, binary16 [6][1152][8]
+    const float* b2;       // [1152]
+    const void* wpp;       // packed project weights (MFMA fragment order)
+    const float* bp;       // [Cout]
+    void* out;             // [n,7,7,Cout] half
+    void* dbg_dw = nullptr;    // single-stage calls (tests): the depthwise output [n,7,7,1152] half ...
+    void* dbg_gate = nullptr;  // ... and the gate [n,1152] half; nullptr in the forward pass
+    int k, Cout, n;
+    bool skip;
+};
+bool mb7_supported(int dtype, int k, int s, int H, int Cin, int Cexp, int R, int Cout, bool skip);
+std::vector<half_t> pack_mb7_taps(const std::vector<float>& w /* [k*k][C] */, int k, int C);
+void pack_mb7_se(const std::vector<float>& w1t /* [R][C] */, const std::vector<float>& w2 /* [R][C] */, int C, int R,
+                 std::vector<half_t>* w1p, std::vector<half_t>* w2p);
+void launch_mb7(const Mb7Args& a, hipStream_t stream);
+std::string kernel_name_mb7(int k, int Cout, bool skip);
+
 // ---- yolo.hip ---------------------------------------------------------------------------
 // YOLOv3 post-processing (yolo_v3/model.py:125-232): decode + score threshold + per-class NMS.
 struct YoloLayer {

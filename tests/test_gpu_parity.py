@@ -90,14 +90,21 @@ def test_info(handle):
     # ... and the stem launch (option stem_fuse: computed inside block 1's depthwise kernel, stemdw.hip)
     folded = 1 if handle.name == "f16" else 0
     stemdw = 1
+    # round 6, option mb7 (off by default): blocks 13-16 of an f16 handle as one launch each instead of front + squeeze-excite + project
+    mb = 4 if handle.name == "f16" else 0
     try:
         handle.set_option("se_fuse", 0)
         assert handle.info().n_kernels_per_forward == 51 - folded - stemdw
+        handle.set_option("mb7", 1)
+        assert handle.info().n_kernels_per_forward == 51 - folded - stemdw - 2 * mb
         handle.set_option("se_fuse", 2)
+        assert handle.info().n_kernels_per_forward == 36 - folded - stemdw - mb
+        handle.set_option("mb7", 0)
         assert handle.info().n_kernels_per_forward == 36 - folded - stemdw
         handle.set_option("fold12", 0)
         assert handle.info().n_kernels_per_forward == 36 - stemdw
     finally:
+        handle.set_option("mb7", 0)
         handle.set_option("fold12", 1)
         handle.set_option("se_fuse", SE_FUSE_DEFAULT)
     assert b"gfx950" in i.arch and i.compute_units >= 200
