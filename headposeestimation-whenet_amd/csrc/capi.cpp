@@ -6,6 +6,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <exception>
 #include <string>
@@ -14,6 +15,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "engine_internal.h"
 
 // A handle = one primary engine plus, with option "inflight" > 1, replica engines (own streams,
 // activation arena, hipGraphs and a copy of the 8.6-17 MB device weights).  A forward is a chain of
@@ -30,14 +32,42 @@ struct whenet_ctx {
     // one large BLOCKING call (whenet_forward_u8 with n >= fanout_min) is cut into fanout_chunk-crop forwards spread over the
     // engines through their pinned-slot pipelines: copies of chunk i+1 overlap the forward of chunk i, results are bitwise
     // those of one forward (the kernels are batch-invariant).  fanout_min = 0 switches it off.
-    int fanout_min = 256, fanout_chunk = 128, fanout_stage = -1, fanout_depth = 2;
-    // fanout_stage -1 = calibrate: how fast the runtime moves PAGEABLE memory differs from box to box (round 5: the direct form read
-    // 126 k / 90 k / 130 k crops/s on three boxes where pinned staging read 110 / 110 / 107 k), so the first two fan-out calls of
-    // a handle run one form each, time themselves, and the faster one (crops per second) is kept.
+    int fanout_min = 256, fanout_chunk = 128, fanout_stage = 2, fanout_depth = 2;
+    // fanout_stage 2 (round 6, default): the caller's array is registered with the runtime for the duration of the call (2 us when the
+    // pages are resident, ~0.2 ms for a fresh 77 MB array; profiles/r06/hostreg_probe.txt), so every chunk's H2D copy is asynchronous:
+    // ONE host thread enqueues everything, and chunk c's copy starts when chunk c-1's is done (stream-ordered across the engines) --
+    // the chunks arrive in order at the link's full rate instead of two engines' copies sharing it (chunk 0 after 0.17 ms, not 0.68).
+    // 0 / 1: round 5's forms (pinned staging / the runtime's pageable path, one host thread per engine).
+    // -1 = calibrate between 0 and 1: how fast the runtime moves PAGEABLE memory differs from box to box (round 5: the direct form read
+    // 126 k / 90 k / 130 k crops/s on three boxes where pinned staging read 110 / 110 / 107 k).  Calls 0 and 1 run one form each UNTIMED
+    // (slots, arena growth, graph captures and lane streams are one-time costs of whichever form runs first), calls 2..5 alternate
+    // the two forms timed, the best rate of each is kept and the faster form serves every later call.
     int fanout_calib_calls = 0;
     double fanout_calib_rate[2] = {0.0, 0.0};
+    int fanout_chosen = -1;                                      // the form the last fan-out call ran (whenet_last_error-free diagnosis: option "fanout_stage" read back)
+    // engines of the fan-out beyond primary + replicas: created on the first large call (option "fanout_engines", default 2: measured
+    // 133 k crops/s at N = 512 f16 in every process, against 115-141 k from process to process with 3 and 123-128 k with 4), private
+    // to it -- "inflight", the round-robin cursor and the chains per forward of everything else are not touched (round 6: the class used
+    // to set inflight = 2 behind the caller's back)
+    std::vector<whenet::Engine*> fan;
+    int fanout_engines = 2;
     std::vector<std::pair<std::string, long>> options;           // replayed on new replicas
     whenet::Engine& at(size_t i) { return i == 0 ? *engine : *replicas[i - 1]; }
+    // engine i of a fan-out over `count` engines: primary, replicas, then the private ones
+    whenet::Engine& fan_at(size_t i) {
+        if (i == 0) return *engine;
+        if (i - 1 < replicas.size()) return *replicas[i - 1];
+        return *fan[i - 1 - replicas.size()];
+    }
+    int fan_count() {
+        const int want = std::max(inflight, std::min(fanout_engines, 4));
+        while (1 + int(replicas.size()) + int(fan.size()) < want) {
+            std::unique_ptr<whenet::Engine> r(new whenet::Engine(snapshot.data(), snapshot.size(), device_id, dtype));
+            for (const auto& kv : options) r->set_option(kv.first, kv.second);
+            fan.push_back(r.release());
+        }
+        return want;
+    }
     whenet::Engine& take() {
         whenet::Engine& e = at(next % size_t(inflight));
         next = (next + 1) % size_t(inflight);
@@ -48,6 +78,44 @@ struct whenet_ctx {
 namespace {
 
 thread_local std::string g_create_error;
+
+// Page ranges this library has registered with the runtime for the duration of a fan-out call (fanout_stage 2).  Two handles driven by
+// two threads may be handed adjacent slices of ONE array (whenet_hip/multi.py): the slices share a page, and registering / unregistering
+// it from both sides races inside the runtime (segfaults in 3 of 8 runs of tests/test_multi_device.py).  A call whose pages overlap a
+// range already held falls back to the runtime's pageable path.
+struct HostRegistry {
+    std::mutex mu;
+    std::vector<std::pair<uintptr_t, uintptr_t>> held;
+    bool acquire(const void* p, size_t nbytes, hipError_t* err) {
+        const uintptr_t page = 4096, lo = reinterpret_cast<uintptr_t>(p) & ~(page - 1),
+                        hi = (reinterpret_cast<uintptr_t>(p) + nbytes + page - 1) & ~(page - 1);
+        std::lock_guard<std::mutex> lock(mu);
+        for (const auto& r : held)
+            if (lo < r.second && r.first < hi) {
+                *err = hipErrorUnknown;
+                return false;
+            }
+        *err = hipHostRegister(const_cast<void*>(p), nbytes, hipHostRegisterDefault);
+        if (*err != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        held.emplace_back(lo, hi);
+        return true;
+    }
+    void release(const void* p, size_t nbytes) {
+        const uintptr_t page = 4096, lo = reinterpret_cast<uintptr_t>(p) & ~(page - 1),
+                        hi = (reinterpret_cast<uintptr_t>(p) + nbytes + page - 1) & ~(page - 1);
+        std::lock_guard<std::mutex> lock(mu);
+        (void)hipHostUnregister(const_cast<void*>(p));
+        for (size_t i = 0; i < held.size(); ++i)
+            if (held[i].first == lo && held[i].second == hi) {
+                held.erase(held.begin() + long(i));
+                break;
+            }
+    }
+};
+HostRegistry g_host_registry;
 
 template <typename F>
 int guarded(whenet_t* h, F&& fn) {
@@ -178,6 +246,7 @@ void whenet_destroy(whenet_t* h) {
     if (h == nullptr) return;
     try {
         for (whenet::Engine* e : h->replicas) delete e;
+        for (whenet::Engine* e : h->fan) delete e;
         delete h->engine;
     } catch (...) {
     }
@@ -204,6 +273,8 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
             WHENET_REQUIRE(!h->snapshot.empty() || value == 1, WHENET_EINVAL, "inflight: this handle has no network");
             e.release_aux_streams();
             for (whenet::Engine* r : h->replicas) r->release_aux_streams();
+            for (whenet::Engine* r : h->fan) delete r;            // (rebuilt on the next large call)
+            h->fan.clear();
             while (int(h->replicas.size()) + 1 > value) {
                 delete h->replicas.back();
                 h->replicas.pop_back();
@@ -223,7 +294,14 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
             for (whenet::Engine* r : h->replicas) r->set_option("device_lanes", lanes);
             return;
         }
-        if (k == "fanout_min" || k == "fanout_chunk" || k == "fanout_stage" || k == "fanout_depth") {
+        if (k == "fanout_min" || k == "fanout_chunk" || k == "fanout_stage" || k == "fanout_depth" || k == "fanout_engines") {
+            if (k == "fanout_engines") {
+                WHENET_REQUIRE(value >= 1 && value <= MAX_INFLIGHT_ENGINES, WHENET_EINVAL, "fanout_engines must be 1..4");
+                h->fanout_engines = int(value);
+                for (whenet::Engine* r : h->fan) delete r;
+                h->fan.clear();
+                return;
+            }
             if (k == "fanout_min") {
                 WHENET_REQUIRE(value >= 0, WHENET_EINVAL, "fanout_min must be >= 0 (0 = never)");
                 h->fanout_min = int(std::min<long>(value, 1 << 30));
@@ -231,9 +309,11 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
                 WHENET_REQUIRE(value >= 1 && value <= 4096, WHENET_EINVAL, "fanout_chunk must be 1..4096");
                 h->fanout_chunk = int(value);
             } else if (k == "fanout_stage") {
-                WHENET_REQUIRE(value >= -1 && value <= 1, WHENET_EINVAL, "fanout_stage must be -1 (calibrate), 0 (pinned staging) or 1 (direct)");
+                WHENET_REQUIRE(value >= -1 && value <= 3, WHENET_EINVAL,
+                               "fanout_stage must be -1 (calibrate 0 against 1), 0 (pinned staging), 1 (the runtime's pageable path) or 2 (registered, default)");
                 h->fanout_stage = int(value);
                 h->fanout_calib_calls = 0;
+                h->fanout_calib_rate[0] = h->fanout_calib_rate[1] = 0.0;
             } else {
                 WHENET_REQUIRE(value >= 1 && value <= WHENET_MAX_INFLIGHT, WHENET_EINVAL, "fanout_depth must be 1..4");
                 h->fanout_depth = int(value);
@@ -242,6 +322,7 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
         }
         e.set_option(k, value);
         for (whenet::Engine* r : h->replicas) r->set_option(k, value);
+        for (whenet::Engine* r : h->fan) r->set_option(k, value);
         h->options.emplace_back(k, value);
     });
 }
@@ -250,7 +331,7 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
     return guarded(h, [&](whenet::Engine& e) {
         bool pending = e.has_pending();                 // the caller's own submissions hold slots: leave them alone
         for (whenet::Engine* r : h->replicas) pending = pending || r->has_pending();
-        if (h->fanout_min <= 0 || n < h->fanout_min || n <= h->fanout_chunk || pending) {
+        if (h->fanout_min <= 0 || n < h->fanout_min || n <= h->fanout_chunk || pending || h->snapshot.empty()) {
             e.forward_host(crops, n, ypr, argmax, logits);
             return;
         }
@@ -260,18 +341,74 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
         // by its OWN host thread (the calling thread takes engine 0): staging a chunk is a 9.6 MB memcpy into pinned memory --
         // ~0.6 ms on one core, more than the 0.42 ms the GPU needs for the chunk -- so one thread feeding all engines is the
         // bottleneck (round 5: 105-112 k crops/s at N = 512 whatever the engine count).  Engines share nothing but the device.
-        const int nthreads = h->inflight;
-        const int chunk = h->fanout_chunk, nchunks = (n + chunk - 1) / chunk;
+        const int chunk = h->fanout_chunk;
         int stage = h->fanout_stage;
         const bool calibrating = stage < 0;
-        if (calibrating) stage = h->fanout_calib_calls < 2 ? 1 - h->fanout_calib_calls : (h->fanout_calib_rate[1] >= h->fanout_calib_rate[0] ? 1 : 0);
+        if (calibrating)
+            stage = h->fanout_calib_calls < 6 ? 1 - (h->fanout_calib_calls & 1) : (h->fanout_calib_rate[1] >= h->fanout_calib_rate[0] ? 1 : 0);
         const auto t_start = std::chrono::steady_clock::now();
         // one engine: the chunk itself supplies the concurrency (two chains); several engines: one chain each
-        const int lanes = h->inflight > 1 ? 1 : 2;
+        const int nfan = h->fan_count();
+        const int lanes = nfan > 1 ? 1 : 2;
+        if (stage == 2 || stage == 3) {
+            const bool shared_copy_stream = stage == 2;           // 3 (probe): every engine's own copy stream, chained by events
+            whenet::detail::DeviceGuard guard(h->device_id);
+            const size_t nbytes = size_t(n) * 150528;
+            hipError_t re = hipSuccess;
+            const bool registered = g_host_registry.acquire(crops, nbytes, &re);
+            if (registered || re == hipErrorHostMemoryAlreadyRegistered) {       // (already registered: the caller pinned it)
+                h->fanout_chosen = stage;
+                struct Pending { int eng, ticket, off; };
+                std::vector<Pending> q;
+                size_t head = 0;
+                std::vector<int> outstanding(size_t(nfan), 0);
+                // every chunk's copy goes through ONE stream (the primary engine's copy stream): in order at the link's full rate, and one
+                // stream fewer per engine for the runtime to place on its four hardware queues (with a copy stream per engine the same
+                // call read 102 k or 134 k crops/s from process to process: profiles/r06/host_path_probe.txt)
+                const hipStream_t copy_on = shared_copy_stream ? h->engine->copy_stream_handle() : nullptr;
+                hipEvent_t prev = nullptr;
+                auto collect_head = [&] {
+                    const Pending& p = q[head++];
+                    const size_t o = size_t(p.off);
+                    h->fan_at(size_t(p.eng)).collect(p.ticket, ypr + o * 3, argmax ? argmax + o * 3 : nullptr, logits ? logits + o * 252 : nullptr);
+                    --outstanding[size_t(p.eng)];
+                };
+                std::exception_ptr err;
+                try {
+                    int off = 0, c = 0;
+                    while (off < n) {
+                        // the first two chunks are half-size: the GPU starts after half a chunk's copy
+                        const int want = c < 2 && chunk >= 32 ? chunk / 2 : chunk;
+                        const int cnt = std::min(want, n - off), ei = c % nfan;
+                        while (outstanding[size_t(ei)] >= h->fanout_depth) collect_head();     // (in submission order: engine ei's oldest is reached)
+                        whenet::Engine& eng = h->fan_at(size_t(ei));
+                        const int ticket = eng.submit(crops + size_t(off) * 150528, cnt, 1, lanes, copy_on, shared_copy_stream ? nullptr : prev);
+                        if (!shared_copy_stream) prev = eng.copied_event(ticket);
+                        q.push_back(Pending{ei, ticket, off});
+                        ++outstanding[size_t(ei)];
+                        off += cnt;
+                        ++c;
+                    }
+                    while (head < q.size()) collect_head();
+                } catch (...) {
+                    err = std::current_exception();
+                    for (int i = 0; i < nfan; ++i) {
+                        try { h->fan_at(size_t(i)).abandon_submissions(); } catch (...) {}
+                    }
+                }
+                if (registered) g_host_registry.release(crops, nbytes);
+                if (err) std::rethrow_exception(err);
+                return;
+            }
+            stage = 1;                                           // the runtime would not register the array: its pageable path
+        }
+        h->fanout_chosen = stage;
+        const int nthreads = nfan;
+        const int nchunks = (n + chunk - 1) / chunk;
         std::vector<std::exception_ptr> errs;
         errs.resize(static_cast<size_t>(nthreads));
         auto drive = [&](int t) {
-            whenet::Engine& eng = h->at(size_t(t));
+            whenet::Engine& eng = h->fan_at(size_t(t));
             struct Pending { int ticket, off; };
             std::vector<Pending> q;
             size_t head = 0;
@@ -289,7 +426,10 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
                 while (head < q.size()) collect_one();
             } catch (...) {
                 errs[size_t(t)] = std::current_exception();
-                eng.abandon_submissions();
+                try {                                            // (on a worker thread nothing may escape: std::terminate)
+                    eng.abandon_submissions();
+                } catch (...) {
+                }
             }
         };
         std::vector<std::thread> workers;
@@ -304,9 +444,11 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
         for (std::thread& w : workers) w.join();
         for (const std::exception_ptr& ep : errs)
             if (ep) std::rethrow_exception(ep);
-        if (calibrating && h->fanout_calib_calls < 2) {
-            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-            h->fanout_calib_rate[stage] = double(n) / (sec > 0 ? sec : 1e-9);
+        if (calibrating && h->fanout_calib_calls < 6) {
+            if (h->fanout_calib_calls >= 2) {                     // (calls 0 and 1 warm both forms up, untimed)
+                const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                h->fanout_calib_rate[stage] = std::max(h->fanout_calib_rate[stage], double(n) / (sec > 0 ? sec : 1e-9));
+            }
             ++h->fanout_calib_calls;
         }
     });
@@ -329,6 +471,7 @@ int whenet_sync(whenet_t* h) {
     return guarded(h, [&](whenet::Engine& e) {
         e.sync();
         for (whenet::Engine* r : h->replicas) r->sync();
+        for (whenet::Engine* r : h->fan) r->sync();
     });
 }
 

@@ -127,6 +127,10 @@ template <> struct Mfma<float> {
 //     v_mfma_f32_32x32x2_f32 (5.3x less matrix time), f32 accumulation as before; the dropped lo*lo term is 2^-22 of the
 //     product.  binary16 subnormal operands are honoured by the matrix cores (tools/probes/mfma_denorm_probe.hip), so the
 //     small lo halves of small activations keep their absolute precision (2^-25).
+//     RANGE (round-5 advice): hi = f16(x) is +-inf for |x| > 65504 and lo = x - hi then NaN -- the form is exact-grade only for
+//     activations inside the binary16 range.  EfficientNet-B0's are O(1..100) behind every BatchNorm (the 512-crop set peaks at ~40);
+//     a snapshot that breaks this shows as NaN angles, never as a silently wrong number, and option split_pw = 0 (the exact-f32
+//     kernels on the same handle) is the way out.  The weights are scaled per layer on the host and cannot overflow.
 template <typename T, bool SP> struct PwOps {
     static constexpr int V = Vec<T>::V;                     // k elements of a lane's fragment
     using VT = typename Vec<T>::type;

@@ -1,5 +1,7 @@
 #include "engine_internal.h"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cmath>
@@ -199,6 +201,9 @@ Engine::~Engine() {
     };
     for (Slot& s : slots_) free_slot_buffers(s);
     free_slot_buffers(host_slot_);
+    if (hout_ypr_) (void)hipHostFree(hout_ypr_);
+    if (hout_amax_) (void)hipHostFree(hout_amax_);
+    if (hout_logits_) (void)hipHostFree(hout_logits_);
     void* arena[] = {x0_, x1_, e_, d_, hc_, partial_, gate_, hcount_, in_u8_, o_ypr_, o_amax_, o_logits_, in_f32_, yolo_scratch_};
     for (void* p : arena)
         if (p) (void)hipFree(p);
@@ -1087,14 +1092,40 @@ void Engine::forward_host(const uint8_t* crops, int n, float* ypr, int32_t* argm
     // (Measured, round 4: issuing the copy lane by lane in front of per-lane graphs, so that the first chain runs while the
     //  second lane's crops travel, changes nothing -- 68.5 k vs 69.6 k crops/s at 64 crops: the 9.6 MB copy from pageable
     //  memory is 0.18 ms of a 0.92 ms call, and two graphs on two streams lose what the overlap gains.)
+    ensure_host_out(n);
     WHENET_HIP_CHECK(hipMemcpyAsync(in_u8_, crops, N * IN_BYTES, hipMemcpyHostToDevice, stream_));
     // a blocking call has the GPU to itself whatever "inflight" says: the forward runs as host_lanes_ chains
     run_forward(in_u8_, n, o_ypr_, o_amax_, o_logits_, stream_, host_lanes_);
-    WHENET_HIP_CHECK(hipMemcpyAsync(ypr, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(argmax, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    // results: asynchronous copies into pinned memory, ONE wait (copies into the caller's pageable arrays each wait for the forward
+    // and for each other inside the runtime)
+    WHENET_HIP_CHECK(hipMemcpyAsync(hout_ypr_, o_ypr_, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (argmax) WHENET_HIP_CHECK(hipMemcpyAsync(hout_amax_, o_amax_, N * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     if (logits)
-        WHENET_HIP_CHECK(hipMemcpyAsync(logits, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        WHENET_HIP_CHECK(hipMemcpyAsync(hout_logits_, o_logits_, N * N_LOGITS * sizeof(float), hipMemcpyDeviceToHost, stream_));
     WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    std::memcpy(ypr, hout_ypr_, N * 3 * sizeof(float));
+    if (argmax) std::memcpy(argmax, hout_amax_, N * 3 * sizeof(int32_t));
+    if (logits) std::memcpy(logits, hout_logits_, N * N_LOGITS * sizeof(float));
+}
+
+void Engine::ensure_host_out(int n) {
+    if (n <= hout_cap_) return;
+    // One allocation that covers every blocking call below the fan-out threshold (264 KB of pinned memory), made under a process-wide
+    // lock: growing these buffers (hipHostFree + hipHostMalloc) while another handle's thread was inside its own forward crashed
+    // inside the runtime (2-3 of 8 runs of tests/test_multi_device.py with two handles on one device).
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    WHENET_HIP_CHECK(hipStreamSynchronize(stream_));
+    if (hout_ypr_) (void)hipHostFree(hout_ypr_);
+    if (hout_amax_) (void)hipHostFree(hout_amax_);
+    if (hout_logits_) (void)hipHostFree(hout_logits_);
+    hout_ypr_ = nullptr; hout_amax_ = nullptr; hout_logits_ = nullptr;
+    hout_cap_ = 0;
+    const size_t N = size_t(std::max(n, 256));
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hout_ypr_), N * 3 * sizeof(float), hipHostMallocDefault));
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hout_amax_), N * 3 * sizeof(int32_t), hipHostMallocDefault));
+    WHENET_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hout_logits_), N * N_LOGITS * sizeof(float), hipHostMallocDefault));
+    hout_cap_ = int(N);
 }
 
 // Model.predict on the NORMALISED float32 image (whenet.py:27) + decode: the path for real-valued
@@ -1165,7 +1196,18 @@ void Engine::ensure_slot(Slot& s, int n) {
     s.capacity = n;
 }
 
-int Engine::submit(const uint8_t* crops, int n, int stage, int want_lanes) {
+hipStream_t Engine::copy_stream_handle() {
+    DeviceGuard guard(device_);
+    return copy_stream();
+}
+
+hipEvent_t Engine::copied_event(int ticket) const {
+    for (const Slot& s : slots_)
+        if (s.busy && s.ticket == ticket) return s.copied;
+    throw Error(WHENET_EINVAL, "unknown ticket " + std::to_string(ticket));
+}
+
+int Engine::submit(const uint8_t* crops, int n, int stage, int want_lanes, hipStream_t copy_on, hipEvent_t copy_after) {
     DeviceGuard guard(device_);
     require_model();
     WHENET_REQUIRE(crops != nullptr, WHENET_EINVAL, "crops must not be NULL");
@@ -1184,13 +1226,15 @@ int Engine::submit(const uint8_t* crops, int n, int stage, int want_lanes) {
     // three 64-crop batches in flight.
     // stage 1 (the fan-out of one large blocking call, capi.cpp): straight from the caller's memory on the copy stream -- the
     // host blocks for THIS chunk's DMA only, while the forwards of the chunks before it run.
+    const hipStream_t cs = copy_on != nullptr ? copy_on : copy_stream();
+    if (copy_after != nullptr) WHENET_HIP_CHECK(hipStreamWaitEvent(cs, copy_after, 0));
     if (stage == 1) {
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, crops, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream()));
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, crops, N * IN_BYTES, hipMemcpyHostToDevice, cs));
     } else {
         std::memcpy(slot->h_in, crops, N * IN_BYTES);
-        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, copy_stream()));
+        WHENET_HIP_CHECK(hipMemcpyAsync(slot->d_in, slot->h_in, N * IN_BYTES, hipMemcpyHostToDevice, cs));
     }
-    WHENET_HIP_CHECK(hipEventRecord(slot->copied, copy_stream()));
+    WHENET_HIP_CHECK(hipEventRecord(slot->copied, cs));
     WHENET_HIP_CHECK(hipStreamWaitEvent(stream_, slot->copied, 0));
     run_forward(slot->d_in, n, slot->d_ypr, slot->d_amax, slot->d_logits, stream_, want_lanes);
     WHENET_HIP_CHECK(hipMemcpyAsync(slot->h_ypr, slot->d_ypr, N * 3 * sizeof(float), hipMemcpyDeviceToHost, stream_));

@@ -96,7 +96,14 @@ class Engine {
                         hipStream_t stream);
     void sync();
     void release_aux_streams();
-    int submit(const uint8_t* crops, int n, int stage = 0, int want_lanes = 0);
+    // stage: 0 = through the slot's pinned staging buffer, 1 = DMA straight from the caller's memory (pageable: the host blocks for the
+    // copy; registered: asynchronous).
+    // copy_on: the stream the H2D copy is issued on (default: this engine's own copy stream) -- a fan-out puts every chunk's copy on ONE
+    // stream: in order, at the link's full rate
+    // copy_after: the copy starts only after this event (the previous chunk's copy on ANOTHER engine's copy stream)
+    int submit(const uint8_t* crops, int n, int stage = 0, int want_lanes = 0, hipStream_t copy_on = nullptr, hipEvent_t copy_after = nullptr);
+    hipStream_t copy_stream_handle();
+    hipEvent_t copied_event(int ticket) const;     // recorded when the H2D copy of that submission is done
     void abandon_submissions();
     bool has_pending() const {
         for (const Slot& s : slots_)
@@ -271,6 +278,13 @@ class Engine {
 
     Slot slots_[WHENET_MAX_INFLIGHT];
     Slot host_slot_;                   // pinned staging of small BLOCKING host forwards (forward_host, n <= host_pinned_max_)
+    // pinned landing zone of the RESULTS of larger blocking host forwards: three asynchronous D2H copies and one wait instead of three
+    // synchronous copies into the caller's pageable arrays (round 6)
+    float* hout_ypr_ = nullptr;
+    int32_t* hout_amax_ = nullptr;
+    float* hout_logits_ = nullptr;
+    int hout_cap_ = 0;
+    void ensure_host_out(int n);
     int host_pinned_max_ = 8;      // measured round 5: pinned wins up to 8 crops (B=1 f32 420 vs 445 us), loses at 16-32
     int next_ticket_ = 0;
 };

@@ -130,10 +130,8 @@ class WHENet:
             self._handle = MultiDeviceHandle(snapshot, [int(d) for d in devices], dtype)
         else:
             self._handle = _lib.Handle(snapshot, device=int(device), dtype=dtype)
-        self._inflight = None if inflight is None else int(inflight)
-        self._fanout_ready = False
-        if self._inflight is not None:
-            self._prepare_fanout()
+        if inflight is not None:
+            self._handle.set_option("inflight", int(inflight))
         self.model = _Model(self)
         self.idx_tensor = [idx for idx in range(66)]                       # whenet.py:17-20
         self.idx_tensor = np.array(self.idx_tensor, dtype=np.float32)
@@ -142,16 +140,10 @@ class WHENet:
         self.last_logits = None
         self.last_argmax = None
 
-    FANOUT_MIN = 256          # include/whenet_hip.h "fanout_min"
-
-    def _prepare_fanout(self):
-        """Replica engines for the chunked fan-out of large batches (one-off: weights + a 64-crop arena per engine)."""
-        self._handle.set_option("inflight", 2 if self._inflight is None else self._inflight)
-        self._fanout_ready = True
+    FANOUT_MIN = 256          # include/whenet_hip.h "fanout_min": the library cuts larger blocking calls into chunks over its own
+                              # fan-out engines (created on the first such call; "inflight" and the other entry points are not touched)
 
     def _forward(self, u8: np.ndarray):
-        if not self._fanout_ready and u8.shape[0] >= self.FANOUT_MIN:
-            self._prepare_fanout()
         ypr, am, lg = self._handle.forward(u8, want_logits=True)
         self.last_logits, self.last_argmax = lg, am
         return ypr, am, lg

@@ -36,13 +36,26 @@ class MultiDeviceHandle:
         self._pools: List[ThreadPoolExecutor] = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"whenet-gpu{d}")
                                                  for d in self.devices]
         self._handles = []
-        try:
-            futs = [p.submit(handle_factory, snapshot, device=d, dtype=dtype) for p, d in zip(self._pools, self.devices)]
-            for f in futs:
-                self._handles.append(f.result())
-        except BaseException:
-            self.close()
-            raise
+        futs = [p.submit(handle_factory, snapshot, device=d, dtype=dtype) for p, d in zip(self._pools, self.devices)]
+        made, err = [], None
+        for f in futs:                              # every future is awaited: a handle created AFTER the first failure is still ours
+            try:
+                made.append(f.result())
+            except BaseException as e:              # noqa: BLE001
+                made.append(None)
+                err = err or e
+        if err is not None:
+            for p, h in zip(self._pools, made):     # each created handle is closed on the thread that made it
+                if h is not None:
+                    try:
+                        p.submit(h.close).result()
+                    except Exception:               # noqa: BLE001
+                        pass
+            for p in self._pools:
+                p.shutdown(wait=True)
+            self._pools = []
+            raise err
+        self._handles = made
         self.device = self.devices[0]
 
     # ---- plumbing ---------------------------------------------------------------------------------------------------

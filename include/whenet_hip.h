@@ -37,7 +37,8 @@ extern "C" {
  * 3 (round 4): whenet_launch_stat_t carries the crops and chains of the launch it describes (what whenet_profile
  * actually ran: with option "inflight" > 1 a forward is ONE chain of the whole batch).
  * 4 (round 5): dtype WHENET_F32S; whenet_normalise_table; options pw_staged, split_pw, fanout_min / _chunk / _stage / _depth,
- * host_pinned_max, host_lanes, se_fuse_tiny.  (Additions only: a version-3 caller runs unchanged.) */
+ * host_pinned_max, host_lanes, se_fuse_tiny.  (Additions only: a version-3 caller runs unchanged.)
+ * (round 6, still 4 -- options only: mb7, f2s_mask, se_fuse = 3, fanout_engines, fanout_stage = 2 | 3; the fan-out's default form is 2.) */
 #define WHENET_ABI_VERSION 4
 #define WHENET_API __attribute__((visibility("default")))
 
@@ -57,7 +58,10 @@ extern "C" {
 #define WHENET_F32S 2           /* float32 storage and accumulation as WHENET_F32, the 1x1 products as binary16 hi/lo pairs on the
                                  * f16 matrix cores (w = hi + lo, x = hi + lo; lo_w*hi_x + hi_w*lo_x + hi_w*hi_x: ~22 bits per
                                  * product, 3 f16 MFMAs where WHENET_F32 issues 8 f32 MFMAs).  whenet_info_t.dtype reports
-                                 * WHENET_F32 (the storage type); option "split_pw" 0 runs the exact-f32 kernels on such a handle */
+                                 * WHENET_F32 (the storage type); option "split_pw" 0 runs the exact-f32 kernels on such a handle.
+                                 * Precondition: activations inside the binary16 range (|x| <= 65504; EfficientNet-B0's are O(100)
+                                 * behind every BatchNorm) -- beyond it the hi half is inf and the angles come out NaN, never silently
+                                 * wrong */
 
 #define WHENET_IMG      224
 #define WHENET_NLOGITS  252     /* 120 yaw | 66 pitch | 66 roll  (whenet.py:11-13)          */
@@ -147,14 +151,18 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  (f16) / 49 (f32) dependent launches: whenet_info_t.n_kernels_per_forward).  The caller gives every forward in flight its own output
  *                  buffers; whenet_sync waits for all of them.  Results are bitwise those of n = 1),
  *          "fanout_min" (>= 0, default 256: a blocking whenet_forward_u8 of at least this many crops is cut into
- *                  "fanout_chunk"-crop forwards (default 128); chunk c goes to engine c % inflight through that engine's pinned
- *                  submission slots, at most "fanout_depth" (1..4, default 2) outstanding per engine, and every engine is driven
- *                  by its own host thread for the duration of the call (the calling thread takes engine 0): staging a chunk is
- *                  a 9.6 MB host copy, slower than the GPU's work on it, so the copies of different engines must run in
- *                  parallel.  Results are bitwise those of one forward.  0 = never.  "fanout_stage": 0 = chunks are copied into
- *                  pinned staging first, 1 = DMA straight from the caller's pageable memory, -1 (default) = calibrate: the first
- *                  two fan-out calls of a handle run one form each and the faster is kept (the runtime's pageable path is
- *                  box-dependent: 126 / 90 / 130 k crops/s direct against 110 / 110 / 107 k staged on three boxes, N = 512)),
+ *                  "fanout_chunk"-crop forwards (default 128; the first two are half-size so that the GPU starts early); chunk c goes
+ *                  to engine c % E through that engine's pinned submission slots, at most "fanout_depth" (1..4, default 2)
+ *                  outstanding per engine, E = max("inflight", "fanout_engines").  "fanout_engines" (1..4, default 2): engines beyond
+ *                  the handle's own are created on the first such call and belong to the fan-out alone -- "inflight", the round-robin
+ *                  of the other entry points and their chains per forward are not touched.  Results are bitwise those of one forward.
+ *                  0 = never.  "fanout_stage": 2 (default, round 6) = the caller's array is registered with the runtime for the
+ *                  duration of the call (hipHostRegister / hipHostUnregister: 2 us - 0.2 ms), so the chunk copies are asynchronous:
+ *                  one host thread enqueues everything, all copies travel in order on ONE stream at the link's full rate; an
+ *                  array the runtime will not register -- or whose pages overlap an array another handle's call holds -- takes
+ *                  form 1.  0 / 1 = round 5's forms, one host thread per engine: chunks copied into pinned staging first / the
+ *                  runtime's pageable path.  -1 = calibrate 0 against 1: both forms run once untimed, then twice each timed, the
+ *                  faster serves every later call.  3 (probe) = as 2 with a copy stream per engine),
  *          "host_pinned_max" (0..4096, default 8: a blocking whenet_forward_u8 of at most this many crops travels through a
  *                  pinned staging slot -- one asynchronous H2D, the forward, three asynchronous D2H, ONE wait -- instead of
  *                  four synchronous copies from / to the caller's pageable memory: the latency path of the reference's
@@ -172,6 +180,12 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *                  of 32 rows: 32 cache lines per KB) from global memory; 0 = the direct kernel everywhere.  Another summation
  *                  order: results agree to rounding.  Chosen by layer, never by batch),
  *          "split_pw" (0/1, default 1, WHENET_F32S handles only: 0 runs the exact-f32 kernels -- bitwise a WHENET_F32 handle),
+ *          "mb7" (0/1, default 0, WHENET_F16 handles: blocks 13-16 -- the 7 x 7 stage -- run as ONE launch each, one workgroup per crop
+ *                  with the expanded tensor, the depthwise output, the squeeze-excite gate in LDS (mb7.hip) instead of front + squeeze-
+ *                  excite + project launches.  29 us per launch whatever the batch up to 256 crops: +3 % at batch 512, +-1 % at 64
+ *                  crops x 3 in flight, -4 % one forward at a time, +60 us at batch 1 -- the schedule must not depend on the batch, so it
+ *                  is not the default.  Another rounding path of the same function: binary16 squeeze-excite kernels, other orders of
+ *                  summation; bitwise independent of the batch like every other schedule),
  *          "pw_impl" (0 = MFMA kernels, 1 = scalar-FMA check kernels, same results class) */
 WHENET_API int whenet_set_option(whenet_t* h, const char* key, long value);
 

@@ -105,6 +105,20 @@ def test_errors_propagate_after_every_shard_finished(fake):
         MultiDeviceHandle(b"snap", [], dtype=0, handle_factory=fake)
 
 
+def test_a_failed_construction_closes_every_handle_on_its_own_thread(fake):
+    """Round-5 advice: when one device's handle cannot be created, the handles the OTHER futures created -- including those that
+    finished after the failure was seen -- are closed on the thread that made them, and the error is the first one."""
+    def factory(snapshot, device=0, dtype=0):
+        if device == 1:
+            raise OSError("no such device")
+        return FakeHandle(snapshot, device=device, dtype=dtype)
+
+    with pytest.raises(OSError, match="no such device"):
+        MultiDeviceHandle(b"snap", [0, 1, 2, 3], dtype=0, handle_factory=factory)
+    assert sorted(h.device for h in fake.made) == [0, 2, 3]
+    assert all(h.closed and len(h.threads) == 1 for h in fake.made)
+
+
 def test_min_shard_keeps_small_batches_on_one_device(fake):
     m = MultiDeviceHandle(b"snap", [0, 1, 2, 3], dtype=0, handle_factory=fake, min_shard=16)
     m.forward(np.zeros((20, 224, 224, 3), np.uint8))
@@ -137,20 +151,22 @@ def test_gpu_two_handles_on_one_device_are_bitwise_one_handle(dtype):
 @pytest.mark.gpu
 def test_gpu_large_batch_fanout_is_bitwise_one_forward():
     """get_angle(np.uint8[N >= 256]) is cut into 128-crop forwards over the handle's engines (capi.cpp, option fanout_min):
-    same bits as the single forward, ragged tail, every staging mode / depth / chunk size; errors leave the handle usable."""
+    same bits as the single forward, ragged tail, every staging mode (2 = round 6's default: the caller's array registered for the
+    call, one host thread, copies ordered across the engines) / depth / chunk size; errors leave the handle usable."""
     crops = np.concatenate([synth.scene_crops(200, seed=15), synth.noise_crops(77, seed=16)])      # 277
     from whenet_hip import weights as W
     blob = W.pack(W.synthetic(1234))
     with _lib.Handle(blob, device=0, dtype=_lib.F16) as h:
         h.set_option("fanout_min", 0)
         want = h.forward(crops)
-        for inflight, chunk, stage, depth in ((1, 64, 0, 2), (3, 64, 0, 2), (3, 64, 1, 2), (2, 100, 0, 1), (4, 33, 1, 4), (1, 128, 1, 2), (2, 128, -1, 2)):
+        for inflight, chunk, stage, depth in ((1, 64, 0, 2), (3, 64, 0, 2), (3, 64, 1, 2), (2, 100, 0, 1), (4, 33, 1, 4), (1, 128, 1, 2), (2, 128, -1, 2),
+                                              (1, 64, 2, 2), (2, 128, 2, 2), (3, 40, 2, 1), (4, 33, 2, 4)):
             h.set_option("inflight", inflight)
             h.set_option("fanout_min", 128)
             h.set_option("fanout_chunk", chunk)
             h.set_option("fanout_stage", stage)
             h.set_option("fanout_depth", depth)
-            for _ in range(3 if stage < 0 else 1):                     # (calibration: direct, staged, then the faster of the two)
+            for _ in range(7 if stage < 0 else 1):                     # (calibration: both forms warmed up, two timed calls each, then the faster)
                 got = h.forward(crops)
                 for a, b in zip(got, want):
                     assert np.array_equal(a, b), (inflight, chunk, stage, depth)
@@ -163,3 +179,15 @@ def test_gpu_large_batch_fanout_is_bitwise_one_forward():
         assert np.array_equal(h.collect(t, 9)[0], want[0][:9])
         with pytest.raises(ValueError):
             h.set_option("fanout_depth", 9)
+        # the fan-out's own engines (round 6): "inflight" stays what the caller set, whatever large calls came before
+        h.set_option("inflight", 1)
+        h.set_option("fanout_stage", 2)
+        for engines in (1, 3, 2):
+            h.set_option("fanout_engines", engines)
+            got = h.forward(crops)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), engines
+        with pytest.raises(ValueError):
+            h.set_option("fanout_engines", 5)
+        with pytest.raises(ValueError):
+            h.set_option("fanout_stage", 4)
