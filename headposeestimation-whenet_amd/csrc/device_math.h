@@ -61,6 +61,28 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// XCD-aware placement of a 1-D launch of units * per workgroups (round 6).  Workgroup L of a launch runs on XCD L % 8 (observed; each XCD
+// has its own 4 MB L2).  The `per` members of a unit -- the channel chunks of one (crop, tile) or crop group: they all read the SAME input
+// -- are dealt to ONE XCD instead of round-robin over all eight (a 7 x 7 or 14 x 14 layer then pulled its input through eight L2s: block
+// 12's front kernel fetched 4.5 x its algorithmic bytes, the head conv 7.8 x), and consecutive units rotate over the XCDs.  A pure
+// relabelling of which workgroup does what: results unchanged.  Measured (profiles/r06/ab_xcd_layers.txt, ab_xcd_map_*.txt, 64 crops): the
+// front kernels of the 14 x 14 layers get SLOWER when they run alone (b7-b11: 15.5-21.8 -> 18.7-24.7 us: the chunks of a unit then hit the
+// same L2 lines of one XCD at the same time), one forward at a time loses 1.2 % -- and three forwards in flight GAIN 2.0-2.5 %, batch 512
+// 2.6 % (less traffic on the fabric when every CU is busy); front7 / head7 do not move either way.  `grouped` is chosen per kernel family
+// (engine option "xcd_map", default: all three).
+__device__ __forceinline__ void xcd_unit(int L, int units, int per, int& unit, int& member, bool grouped) {
+    const int full = units & ~7;                           // units in whole rounds of eight
+    if (grouped && L < full * per) {
+        const int slot = L >> 3;
+        member = slot % per;
+        unit = (slot / per) * 8 + (L & 7);
+    } else {                                               // members consecutive: a unit's chunks round-robin over the XCDs
+        const int r = grouped ? L - full * per : L;
+        unit = (grouped ? full : 0) + r / per;
+        member = r % per;
+    }
+}
+
 // Swish of two values with packed f32 arithmetic: v_pk_add_f32 / v_pk_mul_f32 for the three plain steps, the two
 // quarter-rate transcendentals per value (v_exp_f32, v_rcp_f32) unpacked: 3.5 instructions per value instead of 5.5.
 // Same operations in the same order as swish_f<false> (x * rcp(1 + exp2(-x * log2(e)))): same bits.

@@ -231,6 +231,10 @@ class Engine {
                                 // every intermediate tensor in LDS).  Measured (profiles/r06/mb7_*): 29 us per launch whatever the batch up to 256
                                 // crops against 3 x 8 us at one crop and 67 us at 256 -- +3 % at batch 512, +-1 % at 64 x 3 in flight, -4 % one
                                 // forward at a time, +60 us at batch 1.  Not the default: the schedule must not depend on the batch.
+    int xcd_map_ = 7;           // option "xcd_map" (round 6), bit mask: the channel chunks that share an input are dealt to ONE XCD in
+                                // 1 = front.hip / front2.hip, 2 = front7.hip, 4 = head7.hip (device_math.h xcd_unit).  Same bits either way.
+                                // Measured on one box (profiles/r06/ab_xcd_map_*.txt): bit 1 is +2.0-2.5 % at 64 crops x 3 in flight and at
+                                // batch 512 (f16), +1.8 % f32s, -1.2 % one 64-crop forward at a time, nothing at batch 1 / 16; bits 2, 4: +-0.3 %
     bool stem_fuse_ = true;     // option "stem_fuse": uint8 input -- the stem conv is computed inside block 1's depthwise kernel (stemdw.hip)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster

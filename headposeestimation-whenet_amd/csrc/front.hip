@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
                                                             int Cexp, int pad, int KSe, int NTe, int CC, int TH,
                                                             int NSX, int tiles_x, int EH, int EW, int EP, int w_off,
                                                             const float* __restrict__ w1t, int R, int RP, float wsi,
-                                                            const float* __restrict__ in_gate) {
+                                                            const float* __restrict__ in_gate, int ntiles, int chunks, int n, int xcd) {
     // GATED (SP only, round 6): the expand contracts (in_gate[crop] * x) -- block 2 fed by block 1's depthwise output with block 1's
     // project folded into the expand weights (engine.cpp, option fold12); the gate multiplies the float32 operand before it is split.
     // SP (T = float, WHENET_F32S): the expand products as binary16 hi/lo pairs on the f16 matrix cores (device_math.h PwOps);
@@ -77,11 +77,12 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5, lm = lane & 31;
-    const int tile = blockIdx.x;
+    int unit, chunk;
+    xcd_unit(int(blockIdx.x), ntiles * n, chunks, unit, chunk, xcd != 0);    // (device_math.h)
+    const int b = unit / ntiles, tile = unit - b * ntiles;
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-    const int c0 = blockIdx.y * CC;
+    const int c0 = chunk * CC;
     const int ccur = (Cexp - c0 < CC) ? (Cexp - c0) : CC;
-    const int b = blockIdx.z;
     const int oy0 = tyi * TH, ox0 = txi * NSX * P;
     const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
 
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         if (w1t == nullptr) {
             // plain form (wide early layers, whose SE kernels are tiny): the tile's channel sums
             // go to se.hip's full kernel: rpart is [n][ntiles][Cexp] here
-            rpart[(size_t(b) * gridDim.x + tile) * Cexp + c0 + tid] = t;
+            rpart[(size_t(b) * ntiles + tile) * Cexp + c0 + tid] = t;
         }
         s_sum[tid] = t;
     }
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
         const float o2 = __shfl_xor(pair, 2, 64);
         const float tot = (q & 2) ? (o2 + pair) : (pair + o2);         // (a0+a1) + (a2+a3)
         if (q == 0 && j < RP)
-            rpart[((size_t(b) * gridDim.x + tile) * gridDim.y + blockIdx.y) * RP + j] = (j < R) ? tot : 0.0f;
+            rpart[((size_t(b) * ntiles + tile) * chunks + chunk) * RP + j] = (j < R) ? tot : 0.0f;
     }
     STAMP(6);
 }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
 template <typename T, int K, int S, int NTHR, bool SP = false, bool GATED = false>
 void launch_t(const FrontArgs& a, hipStream_t stream) {
     const FrontPlan& p = a.plan;
-    dim3 grid(p.tiles_x * p.tiles_y, p.chunks, a.n);
+    dim3 grid(unsigned(p.tiles_x * p.tiles_y) * unsigned(p.chunks) * unsigned(a.n));     // 1-D: the kernel deals the workgroups to the XCDs (xcd_unit())
     WHENET_REQUIRE(p.lds_bytes <= 160 * 1024, WHENET_EINVAL, "front: the tile plan needs more than 160 KB of LDS");
     static std::atomic<bool> attr[64];           // (zero-initialised, one per instantiation; handles are one per host thread)
     int dev = 0;
@@ -371,7 +372,7 @@ void launch_t(const FrontArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((whenet_front_kernel<T, K, S, NTHR, SP, GATED>), grid, dim3(NTHR), p.lds_bytes, stream,
                        static_cast<const T*>(a.x), static_cast<const T*>(SP ? a.weps : a.wep), a.be, a.wd, a.bd,
                        static_cast<T*>(a.out), a.rpart, a.H, a.Ho, a.Cin, a.Cexp, a.pad, SP ? a.KSes : a.KSe, a.NTe, p.CC, p.TH, p.NSX,
-                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3, a.wsi, a.in_gate);
+                       p.tiles_x, p.EH, p.EW, p.EP, p.w_off, a.w1t, a.R, (a.R + 3) & ~3, a.wsi, a.in_gate, p.tiles_x * p.tiles_y, p.chunks, a.n, a.xcd_grouped ? 1 : 0);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 

@@ -61,6 +61,7 @@ struct F2Params {
     int CC, TH, TXG, tiles_x, EH, EWp, RP, CP;
     int off_stage, off_red, off_sum;
     int R, RPse;
+    int ntiles, chunks, n, xcd;       // launch geometry (1-D grid of ntiles * chunks * n workgroups, xcd_unit())
 };
 
 // BN + Swish of one expand task (32 pixels x 32 channels; this lane: channel ch, four runs of 4 consecutive pixels)
@@ -103,11 +104,12 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: the task / item loops are uniform)
     const int g = lane >> 5, lm = lane & 31;
-    const int tile = blockIdx.x;
+    int unit, chunk;
+    xcd_unit(int(blockIdx.x), p.ntiles * p.n, p.chunks, unit, chunk, p.xcd != 0);
+    const int b = unit / p.ntiles, tile = unit - b * p.ntiles;
     const int tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
-    const int c0 = blockIdx.y * p.CC;
+    const int c0 = chunk * p.CC;
     const int ccur = (p.Cexp - c0 < p.CC) ? (p.Cexp - c0) : p.CC;
-    const int b = blockIdx.z;
     const int H = p.H, Cin = p.Cin, RP = p.RP, CP = p.CP;
     const int oy0 = tyi * p.TH, ox0 = txi * p.TXG * 4;
     const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad - XS;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     if (tid < ccur) {
         float t = 0.0f;
         for (int q = 0; q < ncq; ++q) t += s_red[q * p.CC + tid];
-        if (p.w1t == nullptr) p.rpart[(size_t(b) * gridDim.x + tile) * p.Cexp + c0 + tid] = t;
+        if (p.w1t == nullptr) p.rpart[(size_t(b) * p.ntiles + tile) * p.Cexp + c0 + tid] = t;
         s_sum[tid] = t;
     }
     if (p.w1t == nullptr) {
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
             const float pair = accr + quad_xor1(accr);
             const float tot = pair + quad_xor2(pair);
             if (q == 0)
-                p.rpart[((size_t(b) * gridDim.x + tile) * gridDim.y + blockIdx.y) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
+                p.rpart[((size_t(b) * p.ntiles + tile) * p.chunks + chunk) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
         }
     }
     STAMP(6);
@@ -529,6 +531,7 @@ void launch_f2(const Front2Args& a, hipStream_t stream) {
     p.EH = pl.EH;  p.EWp = pl.EWp;  p.RP = pl.RP;  p.CP = pl.CP;
     p.off_stage = pl.off_stage;  p.off_red = pl.off_red;  p.off_sum = pl.off_sum;
     p.R = a.R;  p.RPse = (a.R + 3) & ~3;
+    p.ntiles = pl.tiles_x * pl.tiles_y;  p.chunks = pl.chunks;  p.n = a.n;  p.xcd = a.xcd_grouped ? 1 : 0;
     WHENET_REQUIRE(pl.lds_bytes <= 160 * 1024, WHENET_EINVAL, "front2: the tile plan needs more than 160 KB of LDS");
     static OncePerDevice attr;
     int dev = 0;
@@ -539,7 +542,7 @@ void launch_f2(const Front2Args& a, hipStream_t stream) {
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((whenet_front2_kernel<K, S, KS, NTHR, XS, GATED>), dim3(pl.tiles_x * pl.tiles_y, pl.chunks, a.n), dim3(NTHR),
+    hipLaunchKernelGGL((whenet_front2_kernel<K, S, KS, NTHR, XS, GATED>), dim3(unsigned(pl.tiles_x * pl.tiles_y) * unsigned(pl.chunks) * unsigned(a.n)), dim3(NTHR),
                        pl.lds_bytes, stream, p);
     WHENET_HIP_CHECK(hipGetLastError());
 }

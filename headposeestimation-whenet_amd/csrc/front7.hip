@@ -56,6 +56,7 @@ struct F7Params {
     int n, Cin, Cexp, NTe, R, RPse;
     int off_w, off_stage, off_red, off_sum;
     float wsi;                         // WHENET_F32S: 2^-shift of the scaled split weights (wep is then the [hi | lo] image pair)
+    int chunks, ngroups, xcd;          // launch geometry: a 1-D grid of chunks * ngroups workgroups (xcd_unit())
 };
 
 // K: depthwise kernel size (3 | 5); KS: k-steps of the expand contraction (Cin / 16); G: crops per workgroup; CC: expanded
@@ -78,8 +79,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, lm = lane & 31;
     const int Cin = p.Cin;
-    const int c0 = blockIdx.x * CC;
-    const int crop0 = blockIdx.y * G;                          // first crop of this group
+    int grp, chunk;
+    xcd_unit(int(blockIdx.x), p.ngroups, p.chunks, grp, chunk, p.xcd != 0);    // (device_math.h)
+    const int c0 = chunk * CC;
+    const int crop0 = grp * G;                                 // first crop of this group
     const int nlast = p.n - 1;
 
     STAMP(0);
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_kernel(const F7Params p) {
             const float pair = accr + quad_xor1(accr);
             const float tot = pair + quad_xor2(pair);
             if (q == 0 && jo < p.RPse && crop0 + cr < p.n)
-                p.rpart[(size_t(crop0 + cr) * gridDim.x + blockIdx.x) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
+                p.rpart[(size_t(crop0 + cr) * p.chunks + chunk) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
         }
     }
     STAMP(6);
@@ -386,8 +389,10 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, lm = lane & 31;
     const int Cin = p.Cin;
-    const int c0 = blockIdx.x * CC;
-    const int crop0 = blockIdx.y * G;
+    int grp, chunk;
+    xcd_unit(int(blockIdx.x), p.ngroups, p.chunks, grp, chunk, p.xcd != 0);
+    const int c0 = chunk * CC;
+    const int crop0 = grp * G;
     const int nlast = p.n - 1;
 
     // ---- prologue: expand weights -> LDS; this wave's strip of pixel rows -> registers (all 24 k-steps: one round trip) --
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(NTHR) void whenet_front7_f32_kernel(const F7Params 
             const float pair = accr + quad_xor1(accr);
             const float tot = pair + quad_xor2(pair);
             if (q == 0 && jo < p.RPse && crop0 + cr < p.n)
-                p.rpart[(size_t(crop0 + cr) * gridDim.x + blockIdx.x) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
+                p.rpart[(size_t(crop0 + cr) * p.chunks + chunk) * p.RPse + jo] = (jo < p.R) ? tot : 0.0f;
         }
     }
 }
@@ -703,7 +708,8 @@ void launch_f7(const Front7Args& a, hipStream_t stream) {
         WHENET_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.done[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(pl.chunks, ceil_div(a.n, pl.G)), dim3(NTHR), pl.lds_bytes, stream, p);
+    p.chunks = pl.chunks;  p.ngroups = ceil_div(a.n, pl.G);  p.xcd = a.xcd_grouped ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(unsigned(p.chunks) * unsigned(p.ngroups)), dim3(NTHR), pl.lds_bytes, stream, p);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 

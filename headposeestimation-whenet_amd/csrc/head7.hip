@@ -32,7 +32,7 @@ constexpr int H7_K = 320, H7_KS = H7_K / 16, H7_HW = 49, H7_NC = 64, H7_NT = H7_
 template <int G, int NTHR>
 __global__ __launch_bounds__(NTHR) void whenet_head7_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wep,
                                                             const float* __restrict__ bias, float* __restrict__ feat, int n,
-                                                            int NTILES, int N) {
+                                                            int NTILES, int N, int xcd) {
     constexpr int NWAVE = NTHR / 64;
     constexpr int nstrip = 2 * G;
     constexpr int KS = H7_KS, NT = H7_NT, NC = H7_NC;
@@ -44,8 +44,10 @@ __global__ __launch_bounds__(NTHR) void whenet_head7_kernel(const half_t* __rest
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, lm = lane & 31;
-    const int c0 = blockIdx.x * NC;
-    const int crop0 = blockIdx.y * G;
+    int grp, chunk;
+    xcd_unit(int(blockIdx.x), (n + G - 1) / G, N / NC, grp, chunk, xcd != 0);           // (device_math.h)
+    const int c0 = chunk * NC;
+    const int crop0 = grp * G;
     const int nlast = n - 1;
 
     // ---- prologue: the chunk's weights -> LDS, this wave's strip of pixel rows -> registers -------------------------------
@@ -148,7 +150,7 @@ constexpr int H7F_KS = H7_K / 8, H7F_NC = 32, H7F_KG = 5, H7F_NGRP = H7F_KS / H7
 template <int G, bool SP>
 __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* __restrict__ x, const float* __restrict__ wep,
                                                                    const float* __restrict__ bias, float* __restrict__ feat, int n,
-                                                                   int NTILES, int N, float wsi) {
+                                                                   int NTILES, int N, float wsi, int xcd) {
     constexpr int NTHR = 128 * G, nstrip = 2 * G, NC = H7F_NC, KG = H7F_KG;
     constexpr int KS = SP ? H7_K / 16 : H7F_KS;                                  // k-steps: 20 of 16 | 40 of 8
     constexpr int NGRP = KS / KG;
@@ -162,8 +164,10 @@ __global__ __launch_bounds__(128 * G) void whenet_head7_f32_kernel(const float* 
     const int lane = tid & 63;
     const int strip = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, lm = lane & 31;
-    const int c0 = blockIdx.x * NC;
-    const int crop0 = blockIdx.y * G;
+    int grp, chunk;
+    xcd_unit(int(blockIdx.x), (n + G - 1) / G, N / NC, grp, chunk, xcd != 0);
+    const int c0 = chunk * NC;
+    const int crop0 = grp * G;
 
     constexpr int nwv = H7F_KS * 64;                                            // 16-byte vectors of the staged image (both forms)
     static_assert(nwv % NTHR == 0, "weight staging: whole vectors per lane");
@@ -254,11 +258,11 @@ template <int G>
 void launch_h7_f32(const Head7Args& a, hipStream_t stream) {
     const size_t lds = size_t(H7F_KS) * 1024 + size_t(2 * G) * 2 * H7F_NC * 4;
     if (a.split)
-        hipLaunchKernelGGL((whenet_head7_f32_kernel<G, true>), dim3(a.N / H7F_NC, ceil_div(a.n, G)), dim3(128 * G), lds, stream,
-                           static_cast<const float*>(a.x), static_cast<const float*>(a.weps), a.bias, a.feat, a.n, a.NTILES, a.N, a.wsi);
+        hipLaunchKernelGGL((whenet_head7_f32_kernel<G, true>), dim3(unsigned(a.N / H7F_NC) * unsigned(ceil_div(a.n, G))), dim3(128 * G), lds, stream,
+                           static_cast<const float*>(a.x), static_cast<const float*>(a.weps), a.bias, a.feat, a.n, a.NTILES, a.N, a.wsi, a.xcd_grouped ? 1 : 0);
     else
-        hipLaunchKernelGGL((whenet_head7_f32_kernel<G, false>), dim3(a.N / H7F_NC, ceil_div(a.n, G)), dim3(128 * G), lds, stream,
-                           static_cast<const float*>(a.x), static_cast<const float*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N, 1.0f);
+        hipLaunchKernelGGL((whenet_head7_f32_kernel<G, false>), dim3(unsigned(a.N / H7F_NC) * unsigned(ceil_div(a.n, G))), dim3(128 * G), lds, stream,
+                           static_cast<const float*>(a.x), static_cast<const float*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N, 1.0f, a.xcd_grouped ? 1 : 0);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 
@@ -266,8 +270,8 @@ template <int G>
 void launch_h7(const Head7Args& a, hipStream_t stream) {
     constexpr int NTHR = 512;
     const size_t lds = size_t(H7_KS) * H7_NT * 1024 + size_t(2 * G) * 2 * H7_NC * 4;
-    hipLaunchKernelGGL((whenet_head7_kernel<G, NTHR>), dim3(a.N / H7_NC, ceil_div(a.n, G)), dim3(NTHR), lds, stream,
-                       static_cast<const half_t*>(a.x), static_cast<const half_t*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N);
+    hipLaunchKernelGGL((whenet_head7_kernel<G, NTHR>), dim3(unsigned(a.N / H7_NC) * unsigned(ceil_div(a.n, G))), dim3(NTHR), lds, stream,
+                       static_cast<const half_t*>(a.x), static_cast<const half_t*>(a.wep), a.bias, a.feat, a.n, a.NTILES, a.N, a.xcd_grouped ? 1 : 0);
     WHENET_HIP_CHECK(hipGetLastError());
 }
 

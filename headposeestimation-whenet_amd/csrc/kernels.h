@@ -151,6 +151,7 @@ struct Head7Args {
     bool split = false;
     const void* weps = nullptr;    // [hi image | lo image]
     float wsi = 1.0f;
+    bool xcd_grouped = false;      // the channel chunks of a crop group on one XCD (device_math.h xcd_unit)
 };
 bool head7_supported(int dtype, int K, int N, int HW);
 void launch_head7(const Head7Args& a, hipStream_t stream);
@@ -222,6 +223,7 @@ struct FrontArgs {
     float wsi = 1.0f;
     const float* in_gate = nullptr; // split only: [n][Cin] f32 -- the expand contracts (in_gate[crop] * x): block 2 fed by block 1's
                                     // depthwise output with block 1's project folded into weps (engine.cpp, option fold12)
+    bool xcd_grouped = false;       // the channel chunks of a (crop, tile) on one XCD (device_math.h xcd_unit; engine option "xcd_map")
 };
 void launch_front(const FrontArgs& a, int dtype, hipStream_t stream);
 std::string kernel_name_front(int dtype, int k, int s, int threads);
@@ -263,6 +265,7 @@ struct Front2Args {
     int R;
     int k, s, H, Ho, Cin, Cexp, pad, KSe, NTe, n;
     Front2Plan plan;
+    bool xcd_grouped = false;       // as FrontArgs::xcd_grouped
 };
 void launch_front2(const Front2Args& a, hipStream_t stream);
 std::string kernel_name_front2(int k, int s, int kse, int threads, int xs, bool gated);
@@ -327,6 +330,7 @@ struct Front7Args {
     bool split = false;
     const void* weps = nullptr;    // [hi image | lo image] of the expand weights
     float wsi = 1.0f;
+    bool xcd_grouped = false;      // the channel chunks of a crop group on one XCD (device_math.h xcd_unit)
 };
 void launch_front7(const Front7Args& a, hipStream_t stream);
 std::string kernel_name_front7(int dtype, int k, const Front7Plan& p, bool split = false);

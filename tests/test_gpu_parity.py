@@ -809,6 +809,23 @@ def test_fused_squeeze_excite_is_bitwise_the_separate_launch(handle, golden):
         assert k3 == handle.info().n_kernels_per_forward - 10
 
 
+def test_xcd_placement_is_a_relabelling(handle, golden):
+    """Option xcd_map (round 6): which XCD a workgroup of the fused front / 7 x 7 / head-conv kernels lands on is a relabelling of
+    workgroups -- every logit bitwise the same for every mask, on batches whose unit counts are and are not multiples of eight."""
+    crops = np.concatenate([golden["crops"], synth.scene_crops(29, seed=41)])          # 37 crops
+    want = {n: handle.forward(crops[:n]) for n in (1, 3, 8, 21, 37)}
+    try:
+        for mask in (0, 1, 2, 4, 7):
+            handle.set_option("xcd_map", mask)
+            for n, w in want.items():
+                got = handle.forward(crops[:n])
+                assert all(np.array_equal(a, b) for a, b in zip(got, w)), (mask, n)
+        with pytest.raises(ValueError):
+            handle.set_option("xcd_map", 8)
+    finally:
+        handle.set_option("xcd_map", 7)
+
+
 def test_front_impl_variants_end_to_end(blob, golden):
     """f16: the network with front.hip on every block (round 2's schedule), with front2.hip on every block, and the
     default per-layer choice -- all within the f16 tolerance of the oracle, each batch-invariant."""
