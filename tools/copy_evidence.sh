@@ -1,12 +1,14 @@
 #!/bin/bash
 # gpurun_out/final (tools/final_round.sh on the GPU box) -> profiles/rNN; prints the numbers the docs quote
-R=$(cd "$(dirname "$0")/.." && pwd); RND=${RND:-r05}; F=$R/gpurun_out/final; P=$R/profiles/$RND
+R=$(cd "$(dirname "$0")/.." && pwd); RND=${RND:-r06}; F=$R/gpurun_out/final; P=$R/profiles/$RND
 cp $F/bench_default.json $F/bench_driver_args.json $F/bench_f16_b1.json $F/bench_f16_b8.json $F/bench_f16_b512.json $F/bench_f32_b64.json \
    $F/layers_default.json $F/layers_f32_b64.json $F/smoke.txt $F/diag.txt $F/f16_error_gpu.txt $F/rocprof_bench.json \
    $F/pmc_f16_b64_c64_by_kernel.txt $F/pmc_f16_b64_c32_by_kernel.txt $F/pmc_f32_b64_c64_by_kernel.txt $F/pmc_traffic_f16_b64.json $F/pmc_traffic_f32_b64.json $P/
 mkdir -p $P
 cp $F/bench_f32s_b64.json $F/layers_f32s_b64.json $F/pmc_f32s_b64_c64_by_kernel.txt $F/pmc_f16_b512_c256_by_kernel.txt $F/staged_splitk_ab.txt \
    $F/host_path_numa_probe.txt $F/fetch_pattern_probe.txt $F/mfma_denorm_probe.txt $P/ 2>/dev/null
+cp $F/mb7_probe_timeline.txt $F/ab_mb7_xcd_f16_b64.txt $F/ab_mb7_xcd_f16_b512.txt $F/ab_xcd_f32s_b64.txt $F/latency_b1_mb7.txt $F/host_path_probe.txt \
+   $F/pmc_f16_b64_c64_mb7_by_kernel.txt $P/ 2>/dev/null
 cp $F/rocprof_stats_f32s/bench_kernel_stats.csv $P/rocprofv3_kernel_stats_f32s_b64.csv 2>/dev/null
 grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" $F/pytest_gpu.txt > $P/pytest_gpu.txt
 cat $F/pmc_c64.log $F/pmc_c32.log $F/pmc_f32_c64.log $F/pmc_f32s_c64.log $F/pmc_c256.log | grep "^pmc pass" > $P/pmc.log
