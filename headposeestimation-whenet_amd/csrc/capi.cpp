@@ -292,6 +292,9 @@ int whenet_set_option(whenet_t* h, const char* key, long value) {
             const long lanes = value > 1 ? 1 : 2;
             e.set_option("device_lanes", lanes);
             for (whenet::Engine* r : h->replicas) r->set_option("device_lanes", lanes);
+            // several forwards share the chip: the XCD-grouped placement of the fused kernels pays at every batch (engine.h xcd_grouped)
+            e.set_option("concurrent", value > 1);
+            for (whenet::Engine* r : h->replicas) r->set_option("concurrent", value > 1);
             return;
         }
         if (k == "fanout_min" || k == "fanout_chunk" || k == "fanout_stage" || k == "fanout_depth" || k == "fanout_engines") {

@@ -69,7 +69,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // front kernels of the 14 x 14 layers get SLOWER when they run alone (b7-b11: 15.5-21.8 -> 18.7-24.7 us: the chunks of a unit then hit the
 // same L2 lines of one XCD at the same time), one forward at a time loses 1.2 % -- and three forwards in flight GAIN 2.0-2.5 %, batch 512
 // 2.6 % (less traffic on the fabric when every CU is busy); front7 / head7 do not move either way.  `grouped` is chosen per kernel family
-// (engine option "xcd_map", default: all three).
+// (engine option "xcd_map", default: all three) and applied when the chip is shared: launches of >= 128 crops, or a handle with
+// several forwards in flight (Engine::xcd_grouped) -- bit-neutral, so the choice may depend on the batch.
 __device__ __forceinline__ void xcd_unit(int L, int units, int per, int& unit, int& member, bool grouped) {
     const int full = units & ~7;                           // units in whole rounds of eight
     if (grouped && L < full * per) {

@@ -250,6 +250,10 @@ void Engine::set_option(const std::string& key, long value) {
         head_fuse_ = value != 0;
         sync();
         drop_graphs();
+    } else if (key == "concurrent") {
+        xcd_always_ = value != 0;
+        sync();
+        drop_graphs();
     } else if (key == "xcd_map") {
         WHENET_REQUIRE(value >= 0 && value <= 7, WHENET_EINVAL, "xcd_map must be a bit mask 0..7 (1 = front / front2, 2 = front7, 4 = head7)");
         xcd_map_ = int(value);
@@ -578,7 +582,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
         a.weps = b.expand.wps;
         a.wsi = b.expand.wsi;
         a.n = n;
-        a.xcd_grouped = (xcd_map_ & 2) != 0;
+        a.xcd_grouped = xcd_grouped(2, n);
         a.plan = front7_plan_for(dtype_, sp.cin, cexp, n);
         R(p + "/front", "front", kernel_name_front7(dtype_, sp.k, a.plan, a.split).c_str(), double(n) * (hw_in * sp.cin + hw_out * cexp) * es,
           2.0 * n * (double(hw_in) * sp.cin * cexp + double(hw_out) * sp.k * sp.k * cexp), [&] { launch_front7(a, s); });
@@ -611,7 +615,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
             a.in_gate = static_cast<const float*>(v.gate);
         }
         a.n = n;
-        a.xcd_grouped = (xcd_map_ & 1) != 0;
+        a.xcd_grouped = xcd_grouped(1, n);
         a.plan = b.f2plan;
         a.plan.threads = front2_threads(b.f2plan, n);
         R(p + "/front", "front", kernel_name_front2(sp.k, sp.s, a.KSe, a.plan.threads, a.plan.xs, a.in_gate != nullptr).c_str(),
@@ -680,7 +684,7 @@ void Engine::enqueue_block(const DevBlock& b, const View& v, const void* in, voi
             a.in_gate = static_cast<const float*>(v.gate);
         }
         a.n = n;
-        a.xcd_grouped = (xcd_map_ & 1) != 0;
+        a.xcd_grouped = xcd_grouped(1, n);
         a.plan = b.fplan;
         a.plan.threads = front_threads(b.fplan, n);
         R(p + "/front", "front", kernel_name_front(dtype_, sp.k, sp.s, a.plan.threads).c_str(), double(n) * (hw_in * a.Cin + hw_out * cexp) * es,
@@ -852,7 +856,7 @@ void Engine::enqueue_forward(const View& v, const uint8_t* d_in, int n, float* d
         a.weps = head_.wps;
         a.wsi = head_.wsi;
         a.n = n;
-        a.xcd_grouped = (xcd_map_ & 4) != 0;
+        a.xcd_grouped = xcd_grouped(4, n);
         R("head", "pw", kernel_name_head7(dtype_, n, a.split).c_str(), double(n) * (49.0 * a.K * es + a.N * 4.0), 2.0 * n * 49.0 * a.K * a.N,
           [&] { launch_head7(a, s); });
         HeadsArgs hargs{};

@@ -235,6 +235,10 @@ class Engine {
                                 // 1 = front.hip / front2.hip, 2 = front7.hip, 4 = head7.hip (device_math.h xcd_unit).  Same bits either way.
                                 // Measured on one box (profiles/r06/ab_xcd_map_*.txt): bit 1 is +2.0-2.5 % at 64 crops x 3 in flight and at
                                 // batch 512 (f16), +1.8 % f32s, -1.2 % one 64-crop forward at a time, nothing at batch 1 / 16; bits 2, 4: +-0.3 %
+    bool xcd_always_ = false;   // option "concurrent" (set by the handle when it owns several engines): other forwards share the chip
+    bool xcd_grouped(int bit, int n) const {      // the grouped placement pays when the chip is full: several forwards in flight, or a
+        return (xcd_map_ & bit) != 0 && (xcd_always_ || n >= 128);     // launch of >= 128 crops; one small forward alone loses 1 % with it
+    }
     bool stem_fuse_ = true;     // option "stem_fuse": uint8 input -- the stem conv is computed inside block 1's depthwise kernel (stemdw.hip)
     bool fold12_ = true;        // option "fold12": block 1's project folded into block 2's expand (f16 + front2.hip on block 2)
     int lanes_ = 2;             // concurrent sub-batch chains per forward (option "lanes"; round 3: 2 -- with the faster

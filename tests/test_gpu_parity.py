@@ -815,15 +815,17 @@ def test_xcd_placement_is_a_relabelling(handle, golden):
     crops = np.concatenate([golden["crops"], synth.scene_crops(29, seed=41)])          # 37 crops
     want = {n: handle.forward(crops[:n]) for n in (1, 3, 8, 21, 37)}
     try:
-        for mask in (0, 1, 2, 4, 7):
+        for mask, concurrent in ((0, 1), (1, 1), (2, 1), (4, 1), (7, 1), (7, 0)):
             handle.set_option("xcd_map", mask)
+            handle.set_option("concurrent", concurrent)        # (1: grouped at every batch, as a handle with inflight > 1; 0: from 128 crops per launch)
             for n, w in want.items():
                 got = handle.forward(crops[:n])
-                assert all(np.array_equal(a, b) for a, b in zip(got, w)), (mask, n)
+                assert all(np.array_equal(a, b) for a, b in zip(got, w)), (mask, concurrent, n)
         with pytest.raises(ValueError):
             handle.set_option("xcd_map", 8)
     finally:
         handle.set_option("xcd_map", 7)
+        handle.set_option("concurrent", 0)
 
 
 def test_front_impl_variants_end_to_end(blob, golden):
