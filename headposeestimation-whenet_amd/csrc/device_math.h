@@ -67,8 +67,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // 12's front kernel fetched 4.5 x its algorithmic bytes, the head conv 7.8 x), and consecutive units rotate over the XCDs.  A pure
 // relabelling of which workgroup does what: results unchanged.  Measured (profiles/r06/ab_xcd_layers.txt, ab_xcd_map_*.txt, 64 crops): the
 // front kernels of the 14 x 14 layers get SLOWER when they run alone (b7-b11: 15.5-21.8 -> 18.7-24.7 us: the chunks of a unit then hit the
-// same L2 lines of one XCD at the same time), one forward at a time loses 1.2 % -- and three forwards in flight GAIN 2.0-2.5 %, batch 512
-// 2.6 % (less traffic on the fabric when every CU is busy); front7 / head7 do not move either way.  `grouped` is chosen per kernel family
+// same L2 lines of one XCD at the same time) -- and three forwards in flight GAIN 0.8 % against the 3-D grid order of rounds 2-5, batch
+// 512 and f32s the same 0.8 % (less traffic on the fabric when every CU is busy); front7 / head7 do not move either way.  `grouped` is chosen per kernel family
 // (engine option "xcd_map", default: all three) and applied when the chip is shared: launches of >= 128 crops, or a handle with
 // several forwards in flight (Engine::xcd_grouped) -- bit-neutral, so the choice may depend on the batch.
 __device__ __forceinline__ void xcd_unit(int L, int units, int per, int& unit, int& member, bool grouped) {
@@ -98,6 +98,22 @@ __device__ __forceinline__ float quad_xor1(float v) {      // DPP quad_perm [1,0
 }
 __device__ __forceinline__ float quad_xor2(float v) {      // DPP quad_perm [2,3,0,1]
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
+// The same for the fused front kernels, whose plain order is the 3-D grid's of rounds 2-5 -- tile fastest, then channel chunk, then crop
+// (for the large layers, whose tile counts are multiples of eight, that order already keeps a tile's chunks on one XCD).
+__device__ __forceinline__ void xcd_front(int L, int ntiles, int chunks, int n, bool grouped, int& crop, int& tile, int& chunk) {
+    if (grouped) {
+        int unit;
+        xcd_unit(L, ntiles * n, chunks, unit, chunk, true);
+        crop = unit / ntiles;
+        tile = unit - crop * ntiles;
+    } else {
+        tile = L % ntiles;
+        const int r = L / ntiles;
+        chunk = r % chunks;
+        crop = r / chunks;
+    }
 }
 
 template <typename T> struct IsF32 { static constexpr bool value = false; };

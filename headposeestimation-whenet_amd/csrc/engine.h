@@ -233,8 +233,8 @@ class Engine {
                                 // forward at a time, +60 us at batch 1.  Not the default: the schedule must not depend on the batch.
     int xcd_map_ = 7;           // option "xcd_map" (round 6), bit mask: the channel chunks that share an input are dealt to ONE XCD in
                                 // 1 = front.hip / front2.hip, 2 = front7.hip, 4 = head7.hip (device_math.h xcd_unit).  Same bits either way.
-                                // Measured on one box (profiles/r06/ab_xcd_map_*.txt): bit 1 is +2.0-2.5 % at 64 crops x 3 in flight and at
-                                // batch 512 (f16), +1.8 % f32s, -1.2 % one 64-crop forward at a time, nothing at batch 1 / 16; bits 2, 4: +-0.3 %
+                                // Measured on one box against the 3-D grid order of rounds 2-5 (profiles/r06/ab_xcd_map_*.txt): +0.8 % at
+                                // 64 crops x 3 in flight, at batch 512 and for f32s; the 14 x 14 front kernels alone get slower with it
     bool xcd_always_ = false;   // option "concurrent" (set by the handle when it owns several engines): other forwards share the chip
     bool xcd_grouped(int bit, int n) const {      // the grouped placement pays when the chip is full: several forwards in flight, or a
         return (xcd_map_ & bit) != 0 && (xcd_always_ || n >= 128);     // launch of >= 128 crops; one small forward alone loses 1 % with it

@@ -77,9 +77,8 @@ __global__ __launch_bounds__(NTHR, 4) void whenet_front_kernel(const T* __restri
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5, lm = lane & 31;
-    int unit, chunk;
-    xcd_unit(int(blockIdx.x), ntiles * n, chunks, unit, chunk, xcd != 0);    // (device_math.h)
-    const int b = unit / ntiles, tile = unit - b * ntiles;
+    int b, tile, chunk;
+    xcd_front(int(blockIdx.x), ntiles, chunks, n, xcd != 0, b, tile, chunk);      // (device_math.h)
     const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int c0 = chunk * CC;
     const int ccur = (Cexp - c0 < CC) ? (Cexp - c0) : CC;

@@ -104,9 +104,8 @@ __global__ __launch_bounds__(NTHR) void whenet_front2_kernel(const F2Params p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: the task / item loops are uniform)
     const int g = lane >> 5, lm = lane & 31;
-    int unit, chunk;
-    xcd_unit(int(blockIdx.x), p.ntiles * p.n, p.chunks, unit, chunk, p.xcd != 0);
-    const int b = unit / p.ntiles, tile = unit - b * p.ntiles;
+    int b, tile, chunk;
+    xcd_front(int(blockIdx.x), p.ntiles, p.chunks, p.n, p.xcd != 0, b, tile, chunk);      // (device_math.h)
     const int tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
     const int c0 = chunk * p.CC;
     const int ccur = (p.Cexp - c0 < p.CC) ? (p.Cexp - c0) : p.CC;

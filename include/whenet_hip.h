@@ -182,8 +182,8 @@ WHENET_API int whenet_get_info(const whenet_t* h, whenet_info_t* out);
  *          "split_pw" (0/1, default 1, WHENET_F32S handles only: 0 runs the exact-f32 kernels -- bitwise a WHENET_F32 handle),
  *          "xcd_map" (bit mask 0..7, default 7: the workgroups of a launch that read the SAME input -- the channel chunks of one crop and
  *                  tile -- are dealt to one XCD (one L2) instead of round-robin over the eight: 1 = the fused expand+depthwise kernels,
- *                  2 = the 7 x 7 form, 4 = the head conv.  A relabelling of workgroups: the same bits.  +2 % with the chip full, -1 % for
- *                  one 64-crop forward alone -- so it is applied to launches of >= 128 crops and to every launch of a handle with
+ *                  2 = the 7 x 7 form, 4 = the head conv.  A relabelling of workgroups: the same bits.  +0.8 % with the chip full, slower for
+ *                  one small forward alone -- so it is applied to launches of >= 128 crops and to every launch of a handle with
  *                  "inflight" > 1),
  *          "mb7" (0/1, default 0, WHENET_F16 handles: blocks 13-16 -- the 7 x 7 stage -- run as ONE launch each, one workgroup per crop
  *                  with the expanded tensor, the depthwise output, the squeeze-excite gate in LDS (mb7.hip) instead of front + squeeze-

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 # traffic JSON and bench.py only prints a traffic figure whose crops per launch equal the profiled launch's.
 LB=${3:-$B}
 # (--dump-layers: the chain's launch list of THIS command, which tools/pmc_summary.py uses to name every dispatch's layer)
-CMD="python $R/bench.py --dtype $DT --batch $LB --lanes 1 --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-serial --no-sweep --no-repeat --profile-iters 1 --no-graph --dump-layers $R/gpurun_out/pmc_${DT}_b${B}_c${LB}_layers.json $PMC_EXTRA"
+CMD="python $R/bench.py --dtype $DT --batch $LB --lanes 1 --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-serial --no-sweep --no-repeat --profile-iters 1 --no-graph --opt concurrent=1 --dump-layers $R/gpurun_out/pmc_${DT}_b${B}_c${LB}_layers.json $PMC_EXTRA"
 i=0
 for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" \
