@@ -29,6 +29,14 @@
 // Bytes a workgroup pulls per block (L2 hits after the first workgroup of an XCD): expand 442 KB + taps 184 KB + squeeze-excite
 // 221 KB + project 442 KB (block 16: 737 KB) = 1.3 MB; HBM traffic per crop: 49 x 192 x 2 read (twice with the skip) + 49 x Cout x 2
 // written -- the algorithmic bytes of the block without any intermediate tensor.
+//
+// MEASURED (profiles/r06/mb7_probe_timeline.txt, pmc_f16_b64_c64_mb7_by_kernel.txt, ab_mb7*.txt; docs/experiments.md 12.3): 29.6 us per
+// launch at one crop, 36.7 us at 256 -- against 3 x 8 us at one crop and 67 us at 256 for front7 + se + project.  Workgroup life 28.6 us =
+// stage input 2.1 | expand + taps 13.1 (+ 2.4 waiting for the slowest wave) | squeeze-excite 3.6 | project 4.6 | combine + store 2.8: the
+// tile phase is issue-bound at two waves per SIMD (423 VALU instructions per wave and tile beside 104 MFMAs; the 96 registers of the
+// crop's expand fragments allow no third wave).  Batch 512 +3 %, 64 crops x 3 in flight +0.5-0.9 %, one forward at a time -4 %, batch 1
+// +61 us: engine option "mb7", OFF by default (a schedule that pays only when every CU holds a crop cannot be chosen by batch size
+// without giving up the bitwise batch invariance).
 #include "device_math.h"
 #include "kernels.h"
 #include "stamps.h"
