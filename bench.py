@@ -353,7 +353,7 @@ def dropin_leg(blob, device):
     rng = np.random.default_rng(0)
     big = rng.integers(0, 256, (512, 224, 224, 3), dtype=np.uint8)
     out = {}
-    for dd in ("f32", "f16"):
+    for dd in ("f32", "f32s", "f16"):        # f32s is the class default (whenet.WHENet(snapshot) with no dtype)
         with whenet.WHENet(snapshot=blob, dtype=dd, device=device) as m:
             one = big[:1]
             lat = []
@@ -371,7 +371,8 @@ def dropin_leg(blob, device):
                 m.get_angle(big)
                 k += 1
             out[f"get_angle_b512_{dd}_crops_s"] = k * 512 / (time.perf_counter() - t0)
-    out["note"] = "whenet.WHENet(...).get_angle(numpy uint8): python + ctypes + H2D + forward + D2H, pageable host memory"
+    out["default_dtype"] = "f32s"
+    out["note"] = "whenet.WHENet(...).get_angle(numpy uint8): python + ctypes + H2D + forward + D2H, pageable host memory; the class default is f32s"
     return out
 
 

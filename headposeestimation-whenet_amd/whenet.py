@@ -17,10 +17,15 @@ Extras that the reference does not have (keyword-only, all optional):
   device=0            GPU ordinal
   devices=[0,1,..]    several GPUs from this one process: one handle + feeder thread per device, the batch of each
                       get_angle call split contiguously over them (whenet_hip/multi.py), same bits
-  dtype='f32'|'f16'|'f32s'   activation / 1x1-weight type (f32 = parity configuration; f32s = float32 storage with the
-                      1x1 products as binary16 hi/lo pairs on the f16 matrix cores, include/whenet_hip.h WHENET_F32S)
-  inflight=1..4       engines per handle that one large get_angle call (N >= 256) is spread over in 128-crop chunks, copies
-                      overlapping forwards, one host thread per engine (include/whenet_hip.h "fanout_min"); default: 2, created at the first such call
+  dtype='f32s'|'f32'|'f16'   activation / 1x1-weight type.  Default (round 6) 'f32s': float32 storage with the 1x1 products as binary16
+                      hi/lo pairs on the f16 matrix cores (include/whenet_hip.h WHENET_F32S) -- the same 1e-3 degree / equal-argmax bar
+                      as 'f32' (the exact-float32 configuration) at 1.37 x its throughput and 0.9 x its batch-1 latency.  Its
+                      precondition is activations inside binary16's range (|x| <= 65504): should a snapshot break it the angles
+                      come out NaN, and this class then switches the handle to the exact-f32 kernels (option split_pw = 0) and
+                      repeats the call -- a warning says so
+  inflight=1..4       engines of the handle for callers that keep several forwards in flight themselves (whenet_forward_u8_device /
+                      submit); one large get_angle call (N >= 256) is cut into 128-crop chunks over the library's own fan-out engines
+                      whatever this is (include/whenet_hip.h "fanout_min", "fanout_engines")
   .predict            alias of get_angle (BASELINE.json words the API as WHENet.predict(crop))
   .last_logits, .last_argmax   what Model.predict returned for the last call, and the bin argmax
 """
@@ -89,7 +94,8 @@ class _Model:
         total = info.params_backbone + info.params_heads
         print(f"Total params: {total:,d}")
         print(f"Backend: libwhenet_hip on {info.device_name.decode()} ({info.arch.decode()}), "
-              f"dtype {'f16' if info.dtype == _lib.F16 else 'f32'}, {info.n_kernels_per_forward} kernels/forward")
+              f"dtype {'f16' if info.dtype == _lib.F16 else ('f32s' if self._outer._dtype == _lib.F32S else 'f32')}, "
+              f"{info.n_kernels_per_forward} kernels/forward")
         print("_" * 78)
 
     def predict(self, x, batch_size=8, **_):
@@ -105,7 +111,7 @@ class _Model:
 
 
 class WHENet:
-    def __init__(self, snapshot=None, *, device=0, dtype="f32", devices=None, inflight=None):
+    def __init__(self, snapshot=None, *, device=0, dtype="f32s", devices=None, inflight=None):
         if isinstance(dtype, str):
             if dtype.lower() not in _DTYPES:
                 raise ValueError(f"dtype must be one of {sorted(set(_DTYPES))}")
@@ -130,6 +136,7 @@ class WHENet:
             self._handle = MultiDeviceHandle(snapshot, [int(d) for d in devices], dtype)
         else:
             self._handle = _lib.Handle(snapshot, device=int(device), dtype=dtype)
+        self._dtype = dtype
         if inflight is not None:
             self._handle.set_option("inflight", int(inflight))
         self.model = _Model(self)
@@ -143,13 +150,30 @@ class WHENet:
     FANOUT_MIN = 256          # include/whenet_hip.h "fanout_min": the library cuts larger blocking calls into chunks over its own
                               # fan-out engines (created on the first such call; "inflight" and the other entry points are not touched)
 
+    def _out_of_range(self, ypr) -> bool:
+        """WHENET_F32S splits activations into binary16 hi/lo halves: beyond |x| = 65504 the hi half is inf and the angles NaN (never a
+        silently wrong number).  Not reachable with EfficientNet-B0 behind BatchNorm in practice; if a snapshot does it, the handle
+        goes over to the exact-float32 kernels for good (option split_pw = 0: bitwise a WHENET_F32 handle)."""
+        if self._dtype != _lib.F32S or np.isfinite(ypr).all():
+            return False
+        import warnings
+        warnings.warn("whenet: activations outside binary16's range with dtype='f32s'; this model now runs the exact-float32 kernels "
+                      "(option split_pw=0)", RuntimeWarning, stacklevel=3)
+        self._handle.set_option("split_pw", 0)
+        self._dtype = _lib.F32
+        return True
+
     def _forward(self, u8: np.ndarray):
         ypr, am, lg = self._handle.forward(u8, want_logits=True)
+        if self._out_of_range(ypr):
+            ypr, am, lg = self._handle.forward(u8, want_logits=True)
         self.last_logits, self.last_argmax = lg, am
         return ypr, am, lg
 
     def _forward_f32(self, x: np.ndarray):
         ypr, am, lg = self._handle.forward_f32(x, want_logits=True)
+        if self._out_of_range(ypr):
+            ypr, am, lg = self._handle.forward_f32(x, want_logits=True)
         self.last_logits, self.last_argmax = lg, am
         return ypr, am, lg
 

@@ -207,6 +207,37 @@ def test_f32s_dropin_class():
     assert np.abs(np.stack([y, p, r], 1) - ref["n9_angles"]).max() <= 1e-3
 
 
+def test_f32s_is_the_class_default_and_leaves_binary16_range_loudly():
+    """Round 6: WHENet(snapshot) with no dtype is the f32s configuration (the reference's callers pass none: demo.py:20,
+    demo_video.py:40).  Its precondition is activations inside binary16's range; a snapshot that breaks it (here: the stem's BatchNorm
+    scale times 1e6) gives NaN angles on the handle -- never a silently wrong number -- and the class then runs the exact-float32
+    kernels on the same handle: bitwise a dtype='f32' model, with a warning."""
+    import whenet
+    ref = dict(np.load(os.path.join(GOLD, "reference_get_angle.npz")))
+    crops = C.crops64()[:9]
+    with whenet.WHENet() as m, whenet.WHENet(dtype="f32s") as ms:
+        assert m._dtype == _lib.F32S
+        got = m.get_angle(crops)
+        assert np.abs(np.stack(got, 1) - ref["n9_angles"]).max() <= 1e-3
+        assert all(np.array_equal(a, b) for a, b in zip(got, ms.get_angle(crops)))
+    w = W.synthetic(1234)
+    w = dict(w)
+    w["stem/bn/gamma"] = w["stem/bn/gamma"] * np.float32(1e6)
+    big = W.pack(w)
+    with _lib.Handle(big, device=0, dtype=_lib.F32S) as h:
+        assert np.isnan(h.forward(crops[:2])[0]).any()                 # the handle alone: NaN, not a wrong number
+    with whenet.WHENet(big, dtype="f32") as m32:
+        want = m32.get_angle(crops[:4])
+    assert all(np.isfinite(a).all() for a in want)
+    with whenet.WHENet(big) as m:
+        with pytest.warns(RuntimeWarning, match="binary16"):
+            got = m.get_angle(crops[:4])
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert m._dtype == _lib.F32
+        got2 = m.get_angle(crops[:4])                                   # (later calls: no warning, the same bits)
+        assert all(np.array_equal(a, b) for a, b in zip(got2, want))
+
+
 @pytest.mark.parametrize("dtype", ["f16", "f32s"])
 def test_staged_splitk_option(blob, dtype):
     """Option pw_staged (round 5): the K >= 1152 / 14x14 K = 672 project GEMMs fetch their activation rows coalesced through per-wave
