@@ -339,11 +339,12 @@ int whenet_forward_u8(whenet_t* h, const uint8_t* crops, int n, float* ypr, int3
             return;
         }
         WHENET_REQUIRE(crops != nullptr && ypr != nullptr, WHENET_EINVAL, "crops and ypr must not be NULL");
-        // get_angle(np.uint8[N,...]) with a large N (whenet.py:22-27 takes any N): chunk c goes to engine c % inflight, at most
-        // fanout_depth outstanding per engine, results land in the caller's arrays at the chunk's offset.  Every engine is driven
-        // by its OWN host thread (the calling thread takes engine 0): staging a chunk is a 9.6 MB memcpy into pinned memory --
-        // ~0.6 ms on one core, more than the 0.42 ms the GPU needs for the chunk -- so one thread feeding all engines is the
-        // bottleneck (round 5: 105-112 k crops/s at N = 512 whatever the engine count).  Engines share nothing but the device.
+        // get_angle(np.uint8[N,...]) with a large N (whenet.py:22-27 takes any N): chunk c goes to engine c % E of the fan-out, at most
+        // fanout_depth outstanding per engine, results land in the caller's arrays at the chunk's offset.  Round 6 (fanout_stage 2): the
+        // array is registered for the call, so this ONE thread enqueues everything and the copies run in order on one stream.  Round 5's
+        // forms (stages 0 / 1, further down): every engine is driven by its OWN host thread (the calling thread takes engine 0) --
+        // staging a chunk is a 9.6 MB memcpy into pinned memory, ~0.6 ms on one core, more than the 0.42 ms the GPU needs for it, and a
+        // copy from pageable memory blocks its caller.  Engines share nothing but the device.
         const int chunk = h->fanout_chunk;
         int stage = h->fanout_stage;
         const bool calibrating = stage < 0;
